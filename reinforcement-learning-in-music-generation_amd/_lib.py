@@ -1,0 +1,82 @@
+"""ctypes binding of libcwlt.so -- the only way product code reaches the HIP kernels.
+
+Fails loudly: a missing library raises ImportError at first use, a non-zero status from any entry
+point raises RuntimeError.  No fallback path exists.
+"""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "libcwlt.so")
+
+CWLT_F32 = 0
+CWLT_BF16 = 1
+ABI_VERSION = 1
+
+_c_int = ctypes.c_int
+_c_i64 = ctypes.c_int64
+_c_f32 = ctypes.c_float
+_c_u64 = ctypes.c_uint64
+_ptr = ctypes.c_void_p
+
+# name -> argtypes; restype is always int (status)
+_SIGNATURES = {
+    "cwlt_abi_version": [],
+    "cwlt_causal_linear_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
+                               _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr],
+    "cwlt_causal_linear_bwd": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
+}
+
+_lib = None
+
+
+def load():
+    """Load libcwlt.so (once) and bind every entry point of include/cwlt.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libcwlt.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.argtypes = argtypes
+        fn.restype = _c_int
+    got = lib.cwlt_abi_version()
+    if got != ABI_VERSION:
+        raise ImportError("libcwlt.so ABI version %d, binding expects %d -- rebuild" % (got, ABI_VERSION))
+    _lib = lib
+    return lib
+
+
+def exported_names():
+    return sorted(_SIGNATURES)
+
+
+def check(status, what):
+    if status != 0:
+        raise RuntimeError("%s failed with status %d (1001 = bad argument, 1002 = bad dtype, "
+                           "otherwise a hipError_t)" % (what, status))
+
+
+def dtype_code(t):
+    import torch
+    if t == torch.float32:
+        return CWLT_F32
+    if t == torch.bfloat16:
+        return CWLT_BF16
+    raise TypeError("libcwlt kernels take float32 or bfloat16 activations, got %s" % t)
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def dev(t, name="tensor"):
+    """Device pointer of a tensor that must already live on the GPU."""
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a GPU tensor: the cwlt hot path has no CPU implementation" % name)
+    return ctypes.c_void_p(t.data_ptr())
