@@ -53,6 +53,85 @@ int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const vo
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                            int64_t lddq, int64_t lddk, int64_t lddv, int dtype, void* stream);
 
+/* ---- fused residual + dropout + LayerNorm ------------------------------------------------------
+ * s = x + dropout_p(a) ; y = LayerNorm(s) * gamma + beta.  Replaces, inside fast_transformers'
+ * TransformerEncoderLayer.forward (built at dqn_policy/model.py:128-137, called :232):
+ *   x = x + self.dropout(attn(...)); x = self.norm1(x); ... ; self.norm2(x + self.dropout(ffn));
+ * and TransformerEncoder's final self.norm(x) (x == NULL, p == 0).
+ * x may be NULL (plain LayerNorm of a); s_out may be NULL; mean/rstd (rows) f32 are saved stats.
+ * D % 4 == 0, D <= 1024.  Dropout masks are regenerated from (seed, element index) in backward. */
+int cwlt_ln_blocks(int64_t rows);
+int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* gamma, const float* beta,
+                                   void* s_out, void* y, float* mean, float* rstd,
+                                   int64_t rows, int D, float eps, float p, uint64_t seed,
+                                   int dtype, void* stream);
+/* dy2 (optional second upstream gradient, summed with dy), ds = d/ds (also the residual gradient),
+ * da = dropout-masked ds (may be NULL or alias ds when p == 0).  part: cwlt_ln_blocks(rows)*3*D f32
+ * workspace; dgamma, dbeta (D) f32; dbias (D) f32 = column sum of da (NULL to skip). */
+int cwlt_add_dropout_layernorm_bwd(const void* dy, const void* dy2, const void* s, const float* gamma,
+                                   const float* mean, const float* rstd, void* ds, void* da,
+                                   float* part, float* dgamma, float* dbeta, float* dbias,
+                                   int64_t rows, int D, float p, uint64_t seed, int dtype, void* stream);
+
+/* ---- deterministic column sums (bias gradients) -------------------------------------------------
+ * out[c] = sum_r x[r*ld + c]; part: cwlt_colsum_blocks(rows)*ncols f32.  Replaces the reductions
+ * autograd runs for nn.Linear bias gradients (dqn_policy/model.py:123,156-161). */
+int cwlt_colsum_blocks(int64_t rows);
+int cwlt_colsum(const void* x, float* part, float* out, int64_t rows, int ncols, int64_t ld,
+                int dtype, void* stream);
+
+/* ---- FFN activation: g = dropout_p(gelu(h + bias)) ----------------------------------------------
+ * Replaces `self.dropout(self.activation(self.linear1(y)))` (activation='gelu' = exact erf,
+ * dqn_policy/model.py:134) with the Linear run bias-free.  bias may be NULL.  F % 4 == 0. */
+int cwlt_rowslab_blocks(int64_t rows);
+int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_t rows, int F,
+                               float p, uint64_t seed, int dtype, void* stream);
+/* dh = dropout_bwd(dg) * gelu'(h + bias); dbias (F) f32 = column sums of dh (NULL to skip);
+ * part: cwlt_rowslab_blocks(rows)*F f32 (needed iff dbias). */
+int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias, void* dh,
+                               float* part, float* dbias, int64_t rows, int F, float p,
+                               uint64_t seed, int dtype, void* stream);
+
+/* ---- positional encoding + dropout --------------------------------------------------------------
+ * y = dropout_p(x + pe[r % T]) -- PositionalEncoding.forward, dqn_policy/model.py:90-92.  pe is the
+ * registered (max_len, D) f32 buffer; pe == NULL gives plain dropout, which is also this op's
+ * backward (dx = dropout with the same seed applied to dy). */
+int cwlt_posenc_dropout(const void* x, const float* pe, void* y, int64_t rows, int T, int D,
+                        float p, uint64_t seed, int dtype, void* stream);
+
+/* ---- compound-word multi-embedding --------------------------------------------------------------
+ * out[r, off_f : off_f+width_f] = table_f[tokens[r, f]] * sqrt(width_f), f = 0..n_attr-1.
+ * Replaces Embeddings.forward x6 + torch.cat (dqn_policy/model.py:67-74,206-221;
+ * ppo_policy/model.py:69-76,208-223; dqn_policy/AIRL_model.py:34-41,108-115).
+ * tables / widths / nrows are HOST arrays (device pointers to f32 tables; widths % 64 == 0). */
+int cwlt_embed_splits(int64_t rows);
+int cwlt_cw_embed_fwd(const int64_t* tokens, const void* const* tables, const int* widths,
+                      const int* nrows, int n_attr, void* out, int64_t rows, int64_t ldo,
+                      int dtype, void* stream);
+/* dtables: one flat f32 buffer, table f's gradient at element offset sum_{g<f} nrows[g]*widths[g];
+ * part: cwlt_embed_splits(rows) * (total table elements) f32.  Deterministic (no atomics). */
+int cwlt_cw_embed_bwd(const int64_t* tokens, const int* widths, const int* nrows, int n_attr,
+                      const void* dout, float* part, float* dtables, int64_t rows, int64_t ldd,
+                      int dtype, void* stream);
+
+/* ---- per-attribute softmax heads ----------------------------------------------------------------
+ * logits (rows, ld), attribute f in columns [sum_{g<f} n_class[g], + n_class[f]) (n_class: HOST
+ * array, each <= 256).  Replaces compute_loss x6 (dqn_policy/model.py:163-197: CE(reduction='none')
+ * * loss_mask, summed) and Softmax + argmax x6 (dqn_policy/IRL_dqn_train.py:244-250,
+ * ppo_policy/ppo_train.py:259-267).  Outputs (each may be NULL): loss_sum (n_attr) =
+ * sum_r mask_r * nll_{r,f} [caller divides by sum(mask)]; argmax (rows, n_attr) int64 = first index
+ * of the largest softmax value; pmax (rows, n_attr) its probability; probs (rows, ldp) the softmax.
+ * loss_part: cwlt_heads_blocks(rows) * n_attr f32. */
+int cwlt_heads_blocks(int64_t rows);
+int cwlt_heads_fwd(const void* logits, const int* n_class, int n_attr, const int64_t* target,
+                   const float* mask, float* loss_part, float* loss_sum, int64_t* argmax,
+                   float* pmax, float* probs, int64_t rows, int64_t ld, int64_t ldp,
+                   int dtype, void* stream);
+/* dlogits = (softmax - onehot(target)) * mask_r * coef[f]; coef (n_attr) f32 on device. */
+int cwlt_heads_ce_bwd(const void* logits, const int* n_class, int n_attr, const int64_t* target,
+                      const float* mask, const float* coef, void* dlogits, int64_t rows, int64_t ld,
+                      int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

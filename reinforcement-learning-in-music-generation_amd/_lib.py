@@ -25,6 +25,21 @@ _SIGNATURES = {
     "cwlt_causal_linear_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr],
     "cwlt_causal_linear_bwd": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
+    "cwlt_ln_blocks": [_c_i64],
+    "cwlt_add_dropout_layernorm_fwd": [_ptr] * 8 + [_c_i64, _c_int, _c_f32, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_add_dropout_layernorm_bwd": [_ptr] * 12 + [_c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_colsum_blocks": [_c_i64],
+    "cwlt_colsum": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_i64, _c_int, _ptr],
+    "cwlt_rowslab_blocks": [_c_i64],
+    "cwlt_bias_gelu_dropout_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_embed_splits": [_c_i64],
+    "cwlt_cw_embed_fwd": [_ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_cw_embed_bwd": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_heads_blocks": [_c_i64],
+    "cwlt_heads_fwd": [_ptr, _ptr, _c_int] + [_ptr] * 7 + [_c_i64, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_heads_ce_bwd": [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
 }
 
 _lib = None
@@ -73,6 +88,19 @@ def dtype_code(t):
 def stream_ptr():
     import torch
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def opt(t, name="tensor"):
+    """Device pointer or NULL."""
+    return None if t is None else dev(t, name)
+
+
+def int_array(values):
+    return (ctypes.c_int * len(values))(*[int(v) for v in values])
+
+
+def ptr_array(tensors):
+    return (ctypes.c_void_p * len(tensors))(*[dev(t).value for t in tensors])
 
 
 def dev(t, name="tensor"):

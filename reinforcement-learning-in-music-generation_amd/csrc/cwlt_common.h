@@ -104,4 +104,15 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32
     return rng_u32(seed, idx) >= thresh;
 }
 
+// ---- host-side helpers shared by the launchers ------------------------------------------------
+static inline uint32_t drop_thresh(float p) {
+    if (p <= 0.f) return 0u;
+    double t = (double)p * 4294967296.0;
+    if (t > 4294967295.0) t = 4294967295.0;
+    return (uint32_t)t;
+}
+// out[c] (+)= scale * sum_b part[b*stride + c], fixed summation order (defined in ln.hip)
+int launch_colsum_finalize(const float* part, float* out, int nblocks, long stride, int ncols, float scale,
+                           int accumulate, hipStream_t st);
+
 }  // namespace cwlt

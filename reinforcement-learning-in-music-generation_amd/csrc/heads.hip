@@ -1,0 +1,235 @@
+// Per-attribute softmax heads over the fused logits row: cross-entropy loss (fwd + bwd), greedy
+// argmax and softmax probabilities, all A attributes of a CW token in one pass.
+//
+// Replaces, from /root/reference/dqn_policy/model.py:163-197 (ppo_policy/model.py:167-199):
+//     6 x [ permute(0,2,1) -> CrossEntropyLoss(reduction='none') -> * loss_mask -> sum / sum(mask) ]
+// and from dqn_policy/IRL_dqn_train.py:244-250, ppo_policy/ppo_train.py:259-267,300-307:
+//     6 x [ Softmax(dim=-1) -> argmax(dim=-1) ]
+// The six skinny logits tensors are one (rows, ld) matrix (one 512 x sum(n_f) GEMM); attribute f
+// owns columns [off_f, off_f + n_f).  One wave per token row; segment max / sum by wave shuffles;
+// per-block loss partials are summed in fixed order (deterministic).  HBM-bound.
+#include "cwlt_common.h"
+
+#define CWLT_MAX_ATTR 8
+#define CWLT_HEAD_MAXV 256  // largest per-attribute vocabulary (4 values per lane)
+
+namespace cwlt {
+
+struct HeadArgs {
+    int n[CWLT_MAX_ATTR];
+    int off[CWLT_MAX_ATTR];
+    int n_attr;
+};
+
+// softmax pieces of one attribute segment held 4-per-lane
+struct Seg {
+    float x[4];
+    float mx, sum;
+};
+
+template <typename T>
+__device__ __forceinline__ Seg load_seg(const T* row, int off, int n, int lane) {
+    Seg s;
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        s.x[j] = c < n ? load1(row + off + c) : -INFINITY;
+        m = fmaxf(m, s.x[j]);
+    }
+    s.mx = wave_max(m);
+    float e = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = lane + 64 * j;
+        if (c < n) e += expf(s.x[j] - s.mx);
+    }
+    s.sum = wave_sum(e);
+    return s;
+}
+
+// loss_part[blockIdx.x][A]; optional argmax (rows, A) int64, pmax (rows, A) f32, probs (rows, ldp) f32
+template <typename T>
+__global__ __launch_bounds__(256) void heads_fwd_kernel(const T* __restrict__ logits, HeadArgs a,
+                                                        const int64_t* __restrict__ target,
+                                                        const float* __restrict__ mask, float* __restrict__ loss_part,
+                                                        int64_t* __restrict__ argmax, float* __restrict__ pmax,
+                                                        float* __restrict__ probs, long rows, long ld, long ldp) {
+    __shared__ float red[4][CWLT_MAX_ATTR];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float acc[CWLT_MAX_ATTR];
+#pragma unroll
+    for (int f = 0; f < CWLT_MAX_ATTR; ++f) acc[f] = 0.f;
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const T* row = logits + r * ld;
+        const float mk = mask ? mask[r] : 1.f;
+#pragma unroll
+        for (int f = 0; f < CWLT_MAX_ATTR; ++f) {
+            if (f >= a.n_attr) break;
+            const int n = a.n[f], off = a.off[f];
+            const Seg s = load_seg(row, off, n, lane);
+            if (target) {
+                long t = target[r * a.n_attr + f];
+                t = t < 0 ? 0 : (t >= n ? n - 1 : t);
+                // x_t lives in lane t & 63, slot t >> 6
+                const int slot = (int)(t >> 6);
+                float xt = slot == 0 ? s.x[0] : (slot == 1 ? s.x[1] : (slot == 2 ? s.x[2] : s.x[3]));
+                xt = __shfl(xt, (int)(t & 63), 64);
+                acc[f] += mk * ((logf(s.sum) + s.mx) - xt);
+            }
+            if (argmax || pmax || probs) {
+                // first index of the largest softmax VALUE (softmax then argmax, as the reference does)
+                float best = -1.f;
+                int bi = 0x7fffffff;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int c = lane + 64 * j;
+                    if (c < n) {
+                        const float p = expf(s.x[j] - s.mx) / s.sum;
+                        if (probs) probs[r * ldp + off + c] = p;
+                        if (p > best) { best = p; bi = c; }
+                    }
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) {
+                    const float ob = __shfl_xor(best, o, 64);
+                    const int oi = __shfl_xor(bi, o, 64);
+                    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+                }
+                if (lane == 0) {
+                    if (argmax) argmax[r * a.n_attr + f] = bi;
+                    if (pmax) pmax[r * a.n_attr + f] = best;
+                }
+            }
+        }
+    }
+    if (loss_part) {
+        if (lane == 0)
+#pragma unroll
+            for (int f = 0; f < CWLT_MAX_ATTR; ++f) red[wave][f] = acc[f];
+        __syncthreads();
+        if (threadIdx.x < a.n_attr)
+            loss_part[(long)blockIdx.x * a.n_attr + threadIdx.x] =
+                (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+    }
+}
+
+// dlogits[r, seg f] = (softmax - onehot(target)) * mask_r * coef[f]; columns outside every segment <- 0
+template <typename T>
+__global__ __launch_bounds__(256) void heads_ce_bwd_kernel(const T* __restrict__ logits, HeadArgs a,
+                                                           const int64_t* __restrict__ target,
+                                                           const float* __restrict__ mask,
+                                                           const float* __restrict__ coef, T* __restrict__ dlogits,
+                                                           long rows, long ld, int ncols_total) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int used = 0;
+    for (int f = 0; f < a.n_attr; ++f) used = max(used, a.off[f] + a.n[f]);
+    for (long r = (long)blockIdx.x * 4 + wave; r < rows; r += (long)gridDim.x * 4) {
+        const T* row = logits + r * ld;
+        T* drow = dlogits + r * ld;
+        const float mk = mask ? mask[r] : 1.f;
+#pragma unroll
+        for (int f = 0; f < CWLT_MAX_ATTR; ++f) {
+            if (f >= a.n_attr) break;
+            const int n = a.n[f], off = a.off[f];
+            const Seg s = load_seg(row, off, n, lane);
+            long t = target[r * a.n_attr + f];
+            t = t < 0 ? 0 : (t >= n ? n - 1 : t);
+            const float w = mk * coef[f];
+            const float inv = 1.0f / s.sum;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = lane + 64 * j;
+                if (c < n) {
+                    const float p = expf(s.x[j] - s.mx) * inv;
+                    store1(drow + off + c, (p - (c == (int)t ? 1.f : 0.f)) * w);
+                }
+            }
+        }
+        for (int c = used + lane; c < ncols_total; c += 64) store1(drow + c, 0.f);
+    }
+}
+
+static int fill_heads(HeadArgs& a, const int* n_class, int n_attr) {
+    if (!n_class || n_attr <= 0 || n_attr > CWLT_MAX_ATTR) return CWLT_ERR_ARG;
+    int off = 0;
+    for (int f = 0; f < n_attr; ++f) {
+        if (n_class[f] <= 0 || n_class[f] > CWLT_HEAD_MAXV) return CWLT_ERR_ARG;
+        a.n[f] = n_class[f];
+        a.off[f] = off;
+        off += n_class[f];
+    }
+    for (int f = n_attr; f < CWLT_MAX_ATTR; ++f) a.n[f] = a.off[f] = 0;
+    a.n_attr = n_attr;
+    return CWLT_OK;
+}
+
+}  // namespace cwlt
+
+extern "C" {
+
+int cwlt_heads_blocks(int64_t rows) {
+    int64_t b = (rows + 3) / 4;
+    if (b > 1024) b = 1024;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+/* logits (rows, ld): attribute f in columns [sum_{g<f} n_class[g], +n_class[f]); n_class: HOST array.
+ * target (rows, n_attr) int64 and mask (rows) f32 may be NULL (then no loss).  Outputs, each may be
+ * NULL: loss_sum (n_attr) f32 = sum_r mask_r * nll_{r,f}  [needs loss_part: cwlt_heads_blocks(rows)
+ * * n_attr floats]; argmax (rows, n_attr) int64; pmax (rows, n_attr) f32 = softmax value at argmax;
+ * probs (rows, ldp) f32 full softmax. */
+int cwlt_heads_fwd(const void* logits, const int* n_class, int n_attr, const int64_t* target, const float* mask,
+                   float* loss_part, float* loss_sum, int64_t* argmax, float* pmax, float* probs, int64_t rows,
+                   int64_t ld, int64_t ldp, int dtype, void* stream) {
+    using namespace cwlt;
+    HeadArgs a;
+    int e = fill_heads(a, n_class, n_attr);
+    if (e) return e;
+    const int used = a.off[n_attr - 1] + a.n[n_attr - 1];
+    if (!logits || rows < 0 || ld < used) return CWLT_ERR_ARG;
+    if (loss_sum && (!loss_part || !target)) return CWLT_ERR_ARG;
+    if (probs && ldp < used) return CWLT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return loss_sum ? (int)hipMemsetAsync(loss_sum, 0, sizeof(float) * n_attr, st) : CWLT_OK;
+    const int nb = cwlt_heads_blocks(rows);
+    const int64_t* tg = loss_sum ? target : nullptr;
+    float* lp = loss_sum ? loss_part : nullptr;
+    if (dtype == CWLT_F32)
+        hipLaunchKernelGGL((heads_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)logits, a, tg, mask, lp,
+                           argmax, pmax, probs, (long)rows, (long)ld, (long)ldp);
+    else if (dtype == CWLT_BF16)
+        hipLaunchKernelGGL((heads_fwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)logits, a, tg, mask,
+                           lp, argmax, pmax, probs, (long)rows, (long)ld, (long)ldp);
+    else
+        return CWLT_ERR_DTYPE;
+    e = (int)hipGetLastError();
+    if (e || !loss_sum) return e;
+    return launch_colsum_finalize(loss_part, loss_sum, nb, (long)n_attr, n_attr, 1.0f, 0, st);
+}
+
+/* coef (n_attr) f32 on device: upstream gradient of loss_f divided by sum(mask). */
+int cwlt_heads_ce_bwd(const void* logits, const int* n_class, int n_attr, const int64_t* target, const float* mask,
+                      const float* coef, void* dlogits, int64_t rows, int64_t ld, int dtype, void* stream) {
+    using namespace cwlt;
+    HeadArgs a;
+    int e = fill_heads(a, n_class, n_attr);
+    if (e) return e;
+    const int used = a.off[n_attr - 1] + a.n[n_attr - 1];
+    if (!logits || !target || !coef || !dlogits || rows < 0 || ld < used) return CWLT_ERR_ARG;
+    if (rows == 0) return CWLT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = cwlt_heads_blocks(rows);
+    if (dtype == CWLT_F32)
+        hipLaunchKernelGGL((heads_ce_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)logits, a, target,
+                           mask, coef, (float*)dlogits, (long)rows, (long)ld, (int)ld);
+    else if (dtype == CWLT_BF16)
+        hipLaunchKernelGGL((heads_ce_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)logits, a, target,
+                           mask, coef, (bf16_t*)dlogits, (long)rows, (long)ld, (int)ld);
+    else
+        return CWLT_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+}  // extern "C"

@@ -1,0 +1,185 @@
+"""Builder surface of the encoder the reference gets from fast_transformers, MI355X-native.
+
+`TransformerEncoderBuilder.from_kwargs(...).get()` / `RecurrentEncoderBuilder` / `TriangularCausalMask`
+keep the call shape of /root/reference/dqn_policy/model.py:9-11,128-150,231-238 so the model files
+read like the reference's, and the modules keep the package's parameter names
+(`layers.{i}.attention.{query,key,value,out}_projection`, `layers.{i}.{linear1,linear2,norm1,norm2}`,
+`norm`), so reference checkpoints load unchanged.
+
+Each encoder layer is ONE autograd node with an explicit forward/backward schedule:
+  GEMMs (the only MFMA work) go to hipBLASLt through torch.mm/addmm on the activations' dtype;
+  everything between them is a libcwlt HIP kernel -- fused QKV projection feeding the causal
+  linear attention scan in place, residual+dropout+LayerNorm, bias+GELU+dropout -- and the backward
+  folds bias / gamma / beta gradients into the same passes.
+"""
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class TriangularCausalMask:
+    """fast_transformers.masking.TriangularCausalMask(N, device=...): a lower-triangular marker."""
+
+    def __init__(self, N, device="cpu"):
+        self.N = N
+        self.device = device
+        self.lower_triangular = True
+
+
+class _EncoderLayerFn(torch.autograd.Function):
+    """One post-LN encoder layer (fast_transformers TransformerEncoderLayer + AttentionLayer +
+    CausalLinearAttention), x: (N, L, D) -> (N, L, D)."""
+
+    @staticmethod
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, H, p, seeds):
+        N, L, D = x.shape
+        R = N * L
+        adt = x.dtype
+        x2 = x.reshape(R, D)
+        wqkv = torch.cat([wq, wk, wv], 0).to(adt)
+        bqkv = torch.cat([bq, bk, bv], 0).to(adt)
+        wo_a, w1_a, w2_a = wo.to(adt), w1.to(adt), w2.to(adt)
+        g1f, be1f, g2f, be2f, b1f = (ops._f32(t) for t in (g1, be1, g2, be2, b1))
+
+        qkv = torch.addmm(bqkv, x2, wqkv.t())                              # (R, 3D)  MFMA
+        qkv5 = qkv.view(N, L, 3, H, D // H)
+        _, _, _, a, zinv = ops.cla_fwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2])
+        a2 = a.view(R, D)
+        o = torch.addmm(bo.to(adt), a2, wo_a.t())                          # MFMA
+        s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
+        del o
+        h = torch.mm(x1, w1_a.t())                                         # (R, F)  MFMA, bias in next kernel
+        g = ops.gelu_fwd(h, b1f, p, seeds[1])
+        y = torch.addmm(b2.to(adt), g, w2_a.t())                           # MFMA
+        s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
+        del y
+
+        ctx.save_for_backward(x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2,
+                              wqkv, wo_a, w1_a, w2_a, g1f, g2f, b1f)
+        ctx.cfg = (N, L, D, H, p, seeds)
+        return out.view(N, L, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2,
+         wqkv, wo_a, w1_a, w2_a, g1f, g2f, b1f) = ctx.saved_tensors
+        N, L, D, H, p, seeds = ctx.cfg
+        R = N * L
+        dout2 = dout.reshape(R, D)
+
+        ds2, dy, dg2, dbe2, db2 = ops.ln_bwd(dout2, None, s2, g2f, mean2, rstd2, p, seeds[2])
+        dgact = torch.mm(dy, w2_a)                                         # (R, F)
+        dw2 = torch.mm(dy.t(), g)                                          # (D, F)
+        dh, db1 = ops.gelu_bwd(dgact, h, b1f, p, seeds[1])
+        del dgact
+        dx1 = torch.mm(dh, w1_a)                                           # (R, D)
+        dw1 = torch.mm(dh.t(), x1)                                         # (F, D)
+        del dh
+        ds1, do, dg1, dbe1, dbo = ops.ln_bwd(ds2, dx1, s1, g1f, mean1, rstd1, p, seeds[0])
+        da = torch.mm(do, wo_a)                                            # (R, D)
+        dwo = torch.mm(do.t(), a.view(R, D))
+        qkv5 = qkv.view(N, L, 3, H, D // H)
+        dqkv = ops.cla_bwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2], a, zinv, da.view(N, L, H, D // H))
+        dqkv2 = dqkv.view(R, 3 * D)
+        dx = torch.addmm(ds1, dqkv2, wqkv)                                 # residual + projection gradient
+        dwqkv = torch.mm(dqkv2.t(), x2).float()                            # (3D, D)
+        dbqkv = ops.colsum(dqkv2)
+        return (dx.view(N, L, D),
+                dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
+                dwo.float(), dbo, dw1.float(), db1, dw2.float(), db2, dg1, dbe1, dg2, dbe2,
+                None, None, None)
+
+
+class AttentionLayer(nn.Module):
+    """Holds the four projections under fast_transformers' names; the arithmetic is in _EncoderLayerFn."""
+
+    def __init__(self, d_model, n_heads, d_keys, d_values):
+        super().__init__()
+        self.query_projection = nn.Linear(d_model, d_keys * n_heads)
+        self.key_projection = nn.Linear(d_model, d_keys * n_heads)
+        self.value_projection = nn.Linear(d_model, d_values * n_heads)
+        self.out_projection = nn.Linear(d_values * n_heads, d_model)
+        self.n_heads = n_heads
+
+
+class TransformerEncoderLayer(nn.Module):
+    def __init__(self, attention, d_model, d_ff, dropout):
+        super().__init__()
+        self.attention = attention
+        self.linear1 = nn.Linear(d_model, d_ff)
+        self.linear2 = nn.Linear(d_ff, d_model)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.norm2 = nn.LayerNorm(d_model)
+        self.dropout = nn.Dropout(dropout)  # only carries p / train-eval state
+
+    def forward(self, x, attn_mask=None):
+        if attn_mask is not None and not getattr(attn_mask, "lower_triangular", False):
+            raise RuntimeError("CausalLinearAttention only supports full lower triangular masks")
+        p = self.dropout.p if self.training else 0.0
+        seeds = tuple(ops.next_seed() for _ in range(3)) if p > 0 else (0, 0, 0)
+        at = self.attention
+        return _EncoderLayerFn.apply(
+            x, at.query_projection.weight, at.query_projection.bias, at.key_projection.weight, at.key_projection.bias,
+            at.value_projection.weight, at.value_projection.bias, at.out_projection.weight, at.out_projection.bias,
+            self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
+            self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, at.n_heads, p, seeds)
+
+
+class TransformerEncoder(nn.Module):
+    def __init__(self, layers, norm_layer=None):
+        super().__init__()
+        self.layers = nn.ModuleList(layers)
+        self.norm = norm_layer
+
+    def forward(self, x, attn_mask=None, length_mask=None):
+        if length_mask is not None:
+            raise NotImplementedError("the reference never passes a length mask (dqn_policy/model.py:232)")
+        if not x.is_cuda:
+            raise RuntimeError("rlmg_amd encoder runs on the GPU only (no CPU fallback)")
+        for layer in self.layers:
+            x = layer(x, attn_mask)
+        if self.norm is not None:
+            x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
+        return x
+
+
+class _Builder:
+    recurrent = False
+
+    def __init__(self, **kw):
+        self.kw = kw
+
+    @classmethod
+    def from_kwargs(cls, **kw):
+        return cls(**kw)
+
+    def get(self):
+        kw = self.kw
+        if kw.get("attention_type", "causal-linear") != "causal-linear":
+            raise ValueError("only attention_type='causal-linear' is built (the one the reference uses)")
+        if kw.get("activation", "gelu") != "gelu":
+            raise ValueError("only activation='gelu' is built (dqn_policy/model.py:134)")
+        H = kw["n_heads"]
+        dq, dv = kw["query_dimensions"], kw["value_dimensions"]
+        if dq != 64 or dv != 64:
+            raise ValueError("the gfx950 scan kernel is specialised for 64-wide heads (got %d/%d)" % (dq, dv))
+        d_model = dv * H
+        d_ff = kw.get("feed_forward_dimensions", 1024)
+        p = kw.get("dropout", 0.1)
+        if self.recurrent:
+            from .recurrent import RecurrentTransformerEncoder, RecurrentTransformerEncoderLayer
+            layers = [RecurrentTransformerEncoderLayer(AttentionLayer(d_model, H, dq, dv), d_model, d_ff, p)
+                      for _ in range(kw["n_layers"])]
+            return RecurrentTransformerEncoder(layers, nn.LayerNorm(d_model))
+        layers = [TransformerEncoderLayer(AttentionLayer(d_model, H, dq, dv), d_model, d_ff, p)
+                  for _ in range(kw["n_layers"])]
+        return TransformerEncoder(layers, nn.LayerNorm(d_model))
+
+
+class TransformerEncoderBuilder(_Builder):
+    recurrent = False
+
+
+class RecurrentEncoderBuilder(_Builder):
+    recurrent = True

@@ -1,11 +1,20 @@
-"""torch.autograd bindings of the libcwlt kernels (one Function per C-ABI fwd/bwd pair)."""
+"""Python bindings of the libcwlt kernels: raw launch wrappers + torch.autograd Functions.
+
+Everything here runs on the GPU through the C-ABI in include/cwlt.h; there is no CPU path.
+"""
+import math
+
 import torch
 
 from . import _lib
 
 CLA_EPS = 1e-6  # fast_transformers CausalLinearAttention default eps
+LN_EPS = 1e-5   # nn.LayerNorm default, used by fast_transformers' encoder layers
 
 
+# --------------------------------------------------------------------------------------------------
+# helpers
+# --------------------------------------------------------------------------------------------------
 def _row_stride(t):
     """(N, L, H, D) view whose last two dims are dense and whose batch stride is L*row_stride."""
     N, L, H, D = t.shape
@@ -27,6 +36,63 @@ def _as_rows(t):
     return t, ld
 
 
+def _f32(t):
+    """Parameter as a dense f32 device tensor (the kernels read gamma/beta/bias/tables in f32)."""
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.float().contiguous()
+    return t
+
+
+_seed_counter = [0]
+
+
+def next_seed():
+    """Fresh 62-bit dropout key from torch's CPU generator (reproducible under torch.manual_seed)."""
+    _seed_counter[0] += 1
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & ((1 << 62) - 1)
+
+
+# --------------------------------------------------------------------------------------------------
+# causal linear attention
+# --------------------------------------------------------------------------------------------------
+def cla_fwd(q, k, v, eps=CLA_EPS):
+    """q, k, v: (N, L, H, 64) views (row-strided ok) -> out (N, L, H, 64) dense, zinv (N, L, H) f32."""
+    lib = _lib.load()
+    N, L, H, D = q.shape
+    if k.shape != q.shape or v.shape != q.shape:
+        raise ValueError("causal linear attention needs q, k, v of one shape (N, L, H, D)")
+    if q.dtype != k.dtype or q.dtype != v.dtype:
+        raise TypeError("q, k, v dtypes differ")
+    q, ldq = _as_rows(q)
+    k, ldk = _as_rows(k)
+    v, ldv = _as_rows(v)
+    out = torch.empty((N, L, H, D), dtype=q.dtype, device=q.device)
+    zinv = torch.empty((N, L, H), dtype=torch.float32, device=q.device)
+    _lib.check(lib.cwlt_causal_linear_fwd(
+        _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.dev(out), _lib.dev(zinv),
+        N, H, L, D, ldq, ldk, ldv, H * D, float(eps), _lib.dtype_code(q.dtype), _lib.stream_ptr()),
+        "cwlt_causal_linear_fwd")
+    return q, k, v, out, zinv
+
+
+def cla_bwd(q, k, v, out, zinv, dout):
+    """-> dqkv (N, L, 3, H, 64): dq | dk | dv side by side (= gradient of a fused QKV projection)."""
+    lib = _lib.load()
+    N, L, H, D = q.shape
+    dout, lddo = _as_rows(dout)
+    q, ldq = _as_rows(q)
+    k, ldk = _as_rows(k)
+    v, ldv = _as_rows(v)
+    dqkv = torch.empty((N, L, 3, H, D), dtype=q.dtype, device=q.device)
+    ld = 3 * H * D
+    _lib.check(lib.cwlt_causal_linear_bwd(
+        _lib.dev(q), _lib.dev(k), _lib.dev(v), _lib.dev(out), _lib.dev(zinv), _lib.dev(dout, "dout"),
+        _lib.dev(dqkv[:, :, 0]), _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]), N, H, L, D,
+        ldq, ldk, ldv, H * D, lddo, ld, ld, ld, _lib.dtype_code(q.dtype), _lib.stream_ptr()),
+        "cwlt_causal_linear_bwd")
+    return dqkv
+
+
 class CausalLinearAttentionFn(torch.autograd.Function):
     """out = CLA(q, k, v): q, k, v (N, L, H, 64) raw projections, elu+1 applied inside the kernel.
 
@@ -36,44 +102,276 @@ class CausalLinearAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, eps=CLA_EPS):
-        lib = _lib.load()
-        N, L, H, D = q.shape
-        if k.shape != q.shape or v.shape != q.shape:
-            raise ValueError("causal linear attention needs q, k, v of one shape (N, L, H, D)")
-        if q.dtype != k.dtype or q.dtype != v.dtype:
-            raise TypeError("q, k, v dtypes differ")
-        q, ldq = _as_rows(q)
-        k, ldk = _as_rows(k)
-        v, ldv = _as_rows(v)
-        out = torch.empty((N, L, H, D), dtype=q.dtype, device=q.device)
-        zinv = torch.empty((N, L, H), dtype=torch.float32, device=q.device)
-        _lib.check(lib.cwlt_causal_linear_fwd(
-            _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.dev(out), _lib.dev(zinv),
-            N, H, L, D, ldq, ldk, ldv, H * D, float(eps), _lib.dtype_code(q.dtype), _lib.stream_ptr()),
-            "cwlt_causal_linear_fwd")
+        q, k, v, out, zinv = cla_fwd(q, k, v, eps)
         ctx.save_for_backward(q, k, v, out, zinv)
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        lib = _lib.load()
         q, k, v, out, zinv = ctx.saved_tensors
-        N, L, H, D = q.shape
-        dout, lddo = _as_rows(dout)
-        _, ldq = _as_rows(q)
-        _, ldk = _as_rows(k)
-        _, ldv = _as_rows(v)
-        # one (N, L, 3, H, D) buffer: dq|dk|dv side by side = the gradient of a fused QKV projection
-        dqkv = torch.empty((N, L, 3, H, D), dtype=q.dtype, device=q.device)
-        dq, dk, dv = dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2]
-        ld = 3 * H * D
-        _lib.check(lib.cwlt_causal_linear_bwd(
-            _lib.dev(q), _lib.dev(k), _lib.dev(v), _lib.dev(out), _lib.dev(zinv), _lib.dev(dout, "dout"),
-            _lib.dev(dq), _lib.dev(dk), _lib.dev(dv), N, H, L, D,
-            ldq, ldk, ldv, H * D, lddo, ld, ld, ld, _lib.dtype_code(q.dtype), _lib.stream_ptr()),
-            "cwlt_causal_linear_bwd")
-        return dq, dk, dv, None
+        dqkv = cla_bwd(q, k, v, out, zinv, dout)
+        return dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], None
 
 
 def causal_linear_attention(q, k, v, eps=CLA_EPS):
     return CausalLinearAttentionFn.apply(q, k, v, eps)
+
+
+# --------------------------------------------------------------------------------------------------
+# residual + dropout + LayerNorm
+# --------------------------------------------------------------------------------------------------
+def ln_fwd(x, a, gamma, beta, eps=LN_EPS, p=0.0, seed=0, save_s=True):
+    """s = x + dropout(a); y = LN(s).  x may be None.  a: (rows, D) dense.  -> s (or None), y, mean, rstd."""
+    lib = _lib.load()
+    rows, D = a.shape
+    a = a.contiguous()
+    if x is not None:
+        x = x.contiguous()
+    y = torch.empty_like(a)
+    need_s = save_s and (x is not None or p > 0)
+    s = torch.empty_like(a) if need_s else None
+    mean = torch.empty(rows, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
+    _lib.check(lib.cwlt_add_dropout_layernorm_fwd(
+        _lib.opt(x), _lib.dev(a, "a"), _lib.dev(gamma), _lib.dev(beta), _lib.opt(s), _lib.dev(y),
+        _lib.dev(mean), _lib.dev(rstd), rows, D, float(eps), float(p), int(seed),
+        _lib.dtype_code(a.dtype), _lib.stream_ptr()), "cwlt_add_dropout_layernorm_fwd")
+    if save_s and s is None:
+        s = a
+    return s, y, mean, rstd
+
+
+def ln_bwd(dy, dy2, s, gamma, mean, rstd, p=0.0, seed=0, want_dbias=True):
+    """-> ds, da, dgamma, dbeta, dbias.  da is ds itself when p == 0."""
+    lib = _lib.load()
+    rows, D = s.shape
+    dy = dy.contiguous()
+    if dy2 is not None:
+        dy2 = dy2.contiguous()
+    ds = torch.empty_like(s)
+    da = torch.empty_like(s) if p > 0 else ds
+    nb = lib.cwlt_ln_blocks(rows)
+    part = torch.empty(nb * 3 * D, dtype=torch.float32, device=s.device)
+    stats = torch.empty((3, D), dtype=torch.float32, device=s.device)
+    _lib.check(lib.cwlt_add_dropout_layernorm_bwd(
+        _lib.dev(dy, "dy"), _lib.opt(dy2), _lib.dev(s), _lib.dev(gamma), _lib.dev(mean), _lib.dev(rstd),
+        _lib.dev(ds), _lib.dev(da) if p > 0 else None, _lib.dev(part), _lib.dev(stats[0]), _lib.dev(stats[1]),
+        _lib.dev(stats[2]) if want_dbias else None, rows, D, float(p), int(seed),
+        _lib.dtype_code(s.dtype), _lib.stream_ptr()), "cwlt_add_dropout_layernorm_bwd")
+    return ds, da, stats[0], stats[1], (stats[2] if want_dbias else None)
+
+
+class LayerNormFn(torch.autograd.Function):
+    """Plain LayerNorm over the last dim through the fused kernel (x == NULL, p == 0)."""
+
+    @staticmethod
+    def forward(ctx, a, gamma, beta, eps):
+        shape = a.shape
+        a2 = a.reshape(-1, shape[-1])
+        g, b = _f32(gamma), _f32(beta)
+        s, y, mean, rstd = ln_fwd(None, a2, g, b, eps, 0.0, 0, save_s=True)
+        ctx.save_for_backward(s, g, mean, rstd)
+        return y.view(shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, g, mean, rstd = ctx.saved_tensors
+        ds, _, dg, db, _ = ln_bwd(dy.reshape(s.shape), None, s, g, mean, rstd, 0.0, 0, want_dbias=False)
+        return ds.view(dy.shape), dg, db, None
+
+
+def layer_norm(a, gamma, beta, eps=LN_EPS):
+    return LayerNormFn.apply(a, gamma, beta, eps)
+
+
+# --------------------------------------------------------------------------------------------------
+# FFN activation, column sums, positional encoding
+# --------------------------------------------------------------------------------------------------
+def gelu_fwd(h, bias, p=0.0, seed=0):
+    lib = _lib.load()
+    rows, F = h.shape
+    g = torch.empty_like(h)
+    _lib.check(lib.cwlt_bias_gelu_dropout_fwd(_lib.dev(h, "h"), _lib.opt(bias), _lib.dev(g), rows, F, float(p),
+                                              int(seed), _lib.dtype_code(h.dtype), _lib.stream_ptr()),
+               "cwlt_bias_gelu_dropout_fwd")
+    return g
+
+
+def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
+    lib = _lib.load()
+    rows, F = h.shape
+    dg = dg.contiguous()
+    dh = torch.empty_like(h)
+    part = dbias = None
+    if want_dbias:
+        part = torch.empty(lib.cwlt_rowslab_blocks(rows) * F, dtype=torch.float32, device=h.device)
+        dbias = torch.empty(F, dtype=torch.float32, device=h.device)
+    _lib.check(lib.cwlt_bias_gelu_dropout_bwd(_lib.dev(dg, "dg"), _lib.dev(h), _lib.opt(bias), _lib.dev(dh),
+                                              _lib.opt(part), _lib.opt(dbias), rows, F, float(p), int(seed),
+                                              _lib.dtype_code(h.dtype), _lib.stream_ptr()),
+               "cwlt_bias_gelu_dropout_bwd")
+    return dh, dbias
+
+
+def colsum(x):
+    """Deterministic column sums of a (rows, ncols) matrix (row-strided ok) -> (ncols) f32."""
+    lib = _lib.load()
+    rows, ncols = x.shape
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or ncols % 4 != 0:
+        return x.float().sum(0)
+    part = torch.empty(lib.cwlt_colsum_blocks(rows) * ncols, dtype=torch.float32, device=x.device)
+    out = torch.empty(ncols, dtype=torch.float32, device=x.device)
+    _lib.check(lib.cwlt_colsum(_lib.dev(x, "x"), _lib.dev(part), _lib.dev(out), rows, ncols, x.stride(0),
+                               _lib.dtype_code(x.dtype), _lib.stream_ptr()), "cwlt_colsum")
+    return out
+
+
+def posenc_dropout(x, pe, T, p=0.0, seed=0):
+    """x (rows, D) dense; pe (max_len, D) f32 or None -> dropout(x + pe[r % T])."""
+    lib = _lib.load()
+    rows, D = x.shape
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _lib.check(lib.cwlt_posenc_dropout(_lib.dev(x, "x"), _lib.opt(pe), _lib.dev(y), rows, int(T), D, float(p),
+                                       int(seed), _lib.dtype_code(x.dtype), _lib.stream_ptr()),
+               "cwlt_posenc_dropout")
+    return y
+
+
+class PosEncDropoutFn(torch.autograd.Function):
+    """PositionalEncoding.forward (dqn_policy/model.py:90-92): dropout(x + pe[:, :T])."""
+
+    @staticmethod
+    def forward(ctx, x, pe, p, seed):
+        N, T, D = x.shape
+        if T > pe.shape[-2]:
+            raise RuntimeError("sequence length %d exceeds the positional table (%d)" % (T, pe.shape[-2]))
+        ctx.p, ctx.seed, ctx.T = p, seed, T
+        return posenc_dropout(x.reshape(N * T, D), pe.reshape(-1, D), T, p, seed).view(N, T, D)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.p == 0:
+            return dy, None, None, None
+        N, T, D = dy.shape
+        return posenc_dropout(dy.reshape(N * T, D), None, T, ctx.p, ctx.seed).view(N, T, D), None, None, None
+
+
+# --------------------------------------------------------------------------------------------------
+# compound-word embedding
+# --------------------------------------------------------------------------------------------------
+class CWEmbedFn(torch.autograd.Function):
+    """tokens (..., A) int64 + A tables -> (..., sum widths): lut_f(x_f) * sqrt(d_f), concatenated."""
+
+    @staticmethod
+    def forward(ctx, tokens, out_dtype, *tables):
+        lib = _lib.load()
+        A = len(tables)
+        if tokens.shape[-1] != A:
+            raise ValueError("tokens carry %d attributes, model has %d tables" % (tokens.shape[-1], A))
+        if tokens.dtype != torch.int64:
+            raise TypeError("tokens must be int64 (the reference indexes nn.Embedding with .long())")
+        tabs = [_f32(t) for t in tables]
+        widths = [t.shape[1] for t in tabs]
+        nrows = [t.shape[0] for t in tabs]
+        tok = tokens.reshape(-1, A).contiguous()
+        rows = tok.shape[0]
+        dcat = sum(widths)
+        out = torch.empty((rows, dcat), dtype=out_dtype, device=tok.device)
+        _lib.check(lib.cwlt_cw_embed_fwd(_lib.dev(tok, "tokens"), _lib.ptr_array(tabs), _lib.int_array(widths),
+                                         _lib.int_array(nrows), A, _lib.dev(out), rows, dcat,
+                                         _lib.dtype_code(out_dtype), _lib.stream_ptr()), "cwlt_cw_embed_fwd")
+        ctx.save_for_backward(tok)
+        ctx.widths, ctx.nrows = widths, nrows
+        return out.view(*tokens.shape[:-1], dcat)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (tok,) = ctx.saved_tensors
+        widths, nrows = ctx.widths, ctx.nrows
+        A = len(widths)
+        dcat = sum(widths)
+        d2 = dout.reshape(-1, dcat).contiguous()
+        rows = d2.shape[0]
+        total = sum(w * n for w, n in zip(widths, nrows))
+        part = torch.empty(lib.cwlt_embed_splits(rows) * total, dtype=torch.float32, device=d2.device)
+        flat = torch.empty(total, dtype=torch.float32, device=d2.device)
+        _lib.check(lib.cwlt_cw_embed_bwd(_lib.dev(tok), _lib.int_array(widths), _lib.int_array(nrows), A,
+                                         _lib.dev(d2, "dout"), _lib.dev(part), _lib.dev(flat), rows, dcat,
+                                         _lib.dtype_code(d2.dtype), _lib.stream_ptr()), "cwlt_cw_embed_bwd")
+        grads, o = [], 0
+        for w, n in zip(widths, nrows):
+            grads.append(flat[o:o + w * n].view(n, w))
+            o += w * n
+        return (None, None) + tuple(grads)
+
+
+def cw_embed(tokens, tables, out_dtype=torch.float32):
+    return CWEmbedFn.apply(tokens, out_dtype, *tables)
+
+
+# --------------------------------------------------------------------------------------------------
+# per-attribute heads
+# --------------------------------------------------------------------------------------------------
+def heads_forward(logits, n_class, target=None, mask=None, want_argmax=False, want_pmax=False, want_probs=False):
+    """logits (rows, ld).  -> dict(loss_sum (A) f32 | argmax (rows, A) | pmax | probs (rows, sum n))."""
+    lib = _lib.load()
+    rows, ld = logits.shape[0], logits.stride(0)
+    A = len(n_class)
+    dev = logits.device
+    res = {}
+    loss_part = loss_sum = None
+    if target is not None:
+        target = target.reshape(rows, A).contiguous()
+        loss_part = torch.empty(lib.cwlt_heads_blocks(rows) * A, dtype=torch.float32, device=dev)
+        loss_sum = res["loss_sum"] = torch.empty(A, dtype=torch.float32, device=dev)
+    if mask is not None:
+        mask = mask.reshape(rows).float().contiguous()
+    am = res["argmax"] = torch.empty((rows, A), dtype=torch.int64, device=dev) if want_argmax else None
+    pm = res["pmax"] = torch.empty((rows, A), dtype=torch.float32, device=dev) if want_pmax else None
+    ncol = sum(n_class)
+    pr = res["probs"] = torch.empty((rows, ncol), dtype=torch.float32, device=dev) if want_probs else None
+    _lib.check(lib.cwlt_heads_fwd(_lib.dev(logits, "logits"), _lib.int_array(n_class), A, _lib.opt(target),
+                                  _lib.opt(mask), _lib.opt(loss_part), _lib.opt(loss_sum), _lib.opt(am),
+                                  _lib.opt(pm), _lib.opt(pr), rows, ld, ncol, _lib.dtype_code(logits.dtype),
+                                  _lib.stream_ptr()), "cwlt_heads_fwd")
+    return res
+
+
+class HeadsCEFn(torch.autograd.Function):
+    """6 x compute_loss (dqn_policy/model.py:163-197): returns the (A) vector of masked-mean CE losses."""
+
+    @staticmethod
+    def forward(ctx, logits, target, mask, n_class):
+        logits = logits.contiguous()   # dense (rows, W >= sum n_class): the bwd kernel zero-fills cols up to W
+        rows = logits.shape[0]
+        mask_f = mask.reshape(rows).float().contiguous()
+        target = target.reshape(rows, len(n_class)).contiguous()
+        res = heads_forward(logits, n_class, target, mask_f)
+        msum = mask_f.sum()
+        ctx.save_for_backward(logits, target, mask_f, msum)
+        ctx.n_class = n_class
+        return res["loss_sum"] / msum
+
+    @staticmethod
+    def backward(ctx, gloss):
+        lib = _lib.load()
+        logits, target, mask_f, msum = ctx.saved_tensors
+        n_class = ctx.n_class
+        coef = (gloss.float() / msum).contiguous()
+        dlogits = torch.empty_like(logits)
+        _lib.check(lib.cwlt_heads_ce_bwd(_lib.dev(logits), _lib.int_array(n_class), len(n_class), _lib.dev(target),
+                                         _lib.dev(mask_f), _lib.dev(coef), _lib.dev(dlogits), logits.shape[0],
+                                         logits.stride(0), _lib.dtype_code(logits.dtype), _lib.stream_ptr()),
+                   "cwlt_heads_ce_bwd")
+        return dlogits, None, None, None
+
+
+def heads_ce(logits, target, mask, n_class):
+    """logits (rows, >= sum n_class) dense rows; -> (A) losses = sum(mask * nll) / sum(mask) per attribute."""
+    return HeadsCEFn.apply(logits, target, mask, tuple(int(n) for n in n_class))
+
+
+def sqrt_width(w):
+    return math.sqrt(w)

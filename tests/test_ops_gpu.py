@@ -1,0 +1,203 @@
+"""Each fused libcwlt kernel (through the C-ABI) against the plain PyTorch fp32 op chain it replaces."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+import rlmg_amd  # noqa: F401
+from rlmg_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _close(a, b, tol=TOL, what=""):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    err = (a - b).abs().max().item()
+    scale = max(1.0, b.abs().max().item())
+    assert err <= tol * scale, "%s: max abs err %.3e (scale %.2f)" % (what, err, scale)
+
+
+@pytest.mark.parametrize("rows,D", [(1, 512), (37, 512), (1000, 128), (64, 1024), (5, 256)])
+@pytest.mark.parametrize("residual", [True, False])
+def test_add_layernorm_fwd_bwd(cuda, rows, D, residual):
+    g = torch.Generator().manual_seed(rows + D)
+    a = torch.randn(rows, D, generator=g)
+    x = torch.randn(rows, D, generator=g) if residual else None
+    gamma, beta = torch.randn(D, generator=g), torch.randn(D, generator=g)
+    dy, dy2 = torch.randn(rows, D, generator=g), torch.randn(rows, D, generator=g)
+    ar = a.double().requires_grad_(True)
+    xr = x.double().requires_grad_(True) if residual else None
+    gr, br = gamma.double().requires_grad_(True), beta.double().requires_grad_(True)
+    s_ref = ar + xr if residual else ar
+    y_ref = F.layer_norm(s_ref, (D,), gr, br, 1e-5)
+    y_ref.backward((dy + dy2).double())
+    s, y, mean, rstd = ops.ln_fwd(x.to(cuda) if residual else None, a.to(cuda), gamma.to(cuda), beta.to(cuda))
+    _close(y, y_ref, what="y")
+    ds, da, dg, db, dbias = ops.ln_bwd(dy.to(cuda), dy2.to(cuda), s, gamma.to(cuda), mean, rstd)
+    _close(ds, ar.grad, what="ds")
+    assert da is ds
+    _close(dg, gr.grad, tol=2e-4, what="dgamma")
+    _close(db, br.grad, tol=2e-4, what="dbeta")
+    _close(dbias, ar.grad.sum(0), tol=2e-4, what="dbias")
+
+
+def test_layernorm_dropout_statistics_and_bwd_consistency(cuda):
+    rows, D, p = 256, 512, 0.1
+    g = torch.Generator().manual_seed(1)
+    a, x = torch.randn(rows, D, generator=g).to(cuda), torch.randn(rows, D, generator=g).to(cuda)
+    gamma, beta = torch.ones(D, device=cuda), torch.zeros(D, device=cuda)
+    s, y, mean, rstd = ops.ln_fwd(x, a, gamma, beta, p=p, seed=1234)
+    kept = (s - x)                       # dropout(a): 0 or a / (1-p)
+    mask = kept != 0
+    frac = mask.float().mean().item()
+    assert abs(frac - (1 - p)) < 0.01, frac
+    _close(kept[mask], (a / (1 - p))[mask], what="kept scale")
+    s2, _, _, _ = ops.ln_fwd(x, a, gamma, beta, p=p, seed=1234)
+    assert torch.equal(s, s2)            # same seed -> same mask
+    s3, _, _, _ = ops.ln_fwd(x, a, gamma, beta, p=p, seed=99)
+    assert not torch.equal(s, s3)
+    dy = torch.randn(rows, D, generator=g).to(cuda)
+    ds, da, _, _, _ = ops.ln_bwd(dy, None, s, gamma, mean, rstd, p=p, seed=1234)
+    _close(da, ds * mask / (1 - p), what="da = mask * ds / (1-p)")
+
+
+@pytest.mark.parametrize("rows,Fdim", [(3, 2048), (100, 2048), (17, 512), (2000, 64)])
+def test_bias_gelu_fwd_bwd(cuda, rows, Fdim):
+    g = torch.Generator().manual_seed(rows)
+    h, bias, dg = torch.randn(rows, Fdim, generator=g), torch.randn(Fdim, generator=g), torch.randn(rows, Fdim, generator=g)
+    hr, br = h.double().requires_grad_(True), bias.double().requires_grad_(True)
+    ref = F.gelu(hr + br)
+    ref.backward(dg.double())
+    out = ops.gelu_fwd(h.to(cuda), bias.to(cuda))
+    _close(out, ref, what="gelu")
+    dh, dbias = ops.gelu_bwd(dg.to(cuda), h.to(cuda), bias.to(cuda))
+    _close(dh, hr.grad, what="dh")
+    _close(dbias, br.grad, tol=2e-4, what="dbias")
+
+
+def test_bias_gelu_dropout_mask_roundtrip(cuda):
+    rows, Fdim, p = 128, 2048, 0.1
+    h = torch.randn(rows, Fdim, device=cuda)
+    b = torch.zeros(Fdim, device=cuda)
+    out = ops.gelu_fwd(h, b, p=p, seed=5)
+    ref = F.gelu(h)
+    mask = out != 0
+    assert abs(mask.float().mean().item() - (1 - p)) < 0.01
+    _close(out[mask], (ref / (1 - p))[mask], what="kept")
+    dh, _ = ops.gelu_bwd(torch.ones_like(h), h, b, p=p, seed=5)
+    assert torch.equal(dh != 0, mask | (dh != 0)) and ((dh != 0) & ~mask).sum().item() == 0
+
+
+def test_colsum(cuda):
+    x = torch.randn(777, 1536)
+    _close(ops.colsum(x.to(cuda)), x.double().sum(0), tol=2e-4, what="colsum")
+    big = torch.randn(300, 3, 512).to(cuda)
+    _close(ops.colsum(big[:, 1]), big[:, 1].double().sum(0), tol=2e-4, what="strided colsum")
+
+
+def test_posenc_dropout(cuda):
+    N, T, D = 3, 50, 512
+    x = torch.randn(N, T, D)
+    pe = torch.randn(1, 200, D)
+    xr = x.double().requires_grad_(True)
+    ref = xr + pe[:, :T].double()
+    y = ops.PosEncDropoutFn.apply(x.to(cuda).requires_grad_(True), pe.to(cuda), 0.0, 0)
+    _close(y, ref, what="posenc")
+    xg = x.to(cuda).requires_grad_(True)
+    y = ops.PosEncDropoutFn.apply(xg, pe.to(cuda), 0.25, 77)
+    y.backward(torch.ones_like(y))
+    mask = (y != 0)
+    assert abs(mask.float().mean().item() - 0.75) < 0.02
+    _close(xg.grad, mask.float() / 0.75, what="dropout bwd")
+
+
+@pytest.mark.parametrize("widths,nrows", [((128, 256, 64, 512, 128, 128), (56, 135, 18, 87, 18, 25)),
+                                           ((128, 256, 64, 512, 256, 256), (49, 19, 19, 89, 67, 25)),
+                                           ((64,), (7,))])
+@pytest.mark.parametrize("shape", [(1, 1), (2, 50), (4, 333)])
+def test_cw_embed_fwd_bwd(cuda, widths, nrows, shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    tabs = [torch.randn(n, w, generator=g) for n, w in zip(nrows, widths)]
+    tok = torch.stack([torch.randint(0, n, shape, generator=g) for n in nrows], -1)
+    dout = torch.randn(*shape, sum(widths), generator=g)
+    tr = [t.double().requires_grad_(True) for t in tabs]
+    ref = torch.cat([F.embedding(tok[..., i], tr[i]) * math.sqrt(widths[i]) for i in range(len(tabs))], -1)
+    ref.backward(dout.double())
+    td = [t.to(cuda).requires_grad_(True) for t in tabs]
+    out = ops.cw_embed(tok.to(cuda), td)
+    _close(out, ref, tol=1e-6, what="embed")
+    out.backward(dout.to(cuda))
+    for i, t in enumerate(td):
+        _close(t.grad, tr[i].grad, tol=2e-4, what="dtable%d" % i)
+
+
+def test_cw_embed_bwd_is_deterministic(cuda):
+    widths, nrows = (128, 256, 64, 512, 128, 128), (56, 135, 18, 87, 18, 25)
+    tabs = [torch.randn(n, w, device=cuda, requires_grad=True) for n, w in zip(nrows, widths)]
+    tok = torch.stack([torch.randint(0, n, (8, 512)) for n in nrows], -1).to(cuda)
+    dout = torch.randn(8, 512, sum(widths), device=cuda)
+    grads = []
+    for _ in range(2):
+        for t in tabs:
+            t.grad = None
+        ops.cw_embed(tok, tabs).backward(dout)
+        grads.append([t.grad.clone() for t in tabs])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
+@pytest.mark.parametrize("n_class", [(56, 135, 18, 87, 18, 25), (49, 19, 19, 89, 67, 25), (200,)])
+@pytest.mark.parametrize("rows", [1, 50, 1031])
+def test_heads_ce_fwd_bwd_argmax(cuda, n_class, rows):
+    g = torch.Generator().manual_seed(rows)
+    W = sum(n_class) + ((-sum(n_class)) % 64)
+    logits = torch.randn(rows, W, generator=g) * 3
+    target = torch.stack([torch.randint(0, n, (rows,), generator=g) for n in n_class], -1)
+    mask = (torch.rand(rows, generator=g) > 0.2).float()
+    mask[0] = 1.0
+    lr = logits.double().requires_grad_(True)
+    losses, o = [], 0
+    for i, n in enumerate(n_class):
+        ce = F.cross_entropy(lr[:, o:o + n], target[:, i], reduction="none")
+        losses.append((ce * mask.double()).sum() / mask.double().sum())
+        o += n
+    ref = torch.stack(losses)
+    w = torch.randn(len(n_class), generator=g).double()
+    (ref * w).sum().backward()
+    ld = logits.to(cuda).requires_grad_(True)
+    out = ops.heads_ce(ld, target.to(cuda), mask.to(cuda), n_class)
+    _close(out, ref, what="losses")
+    (out * w.float().to(cuda)).sum().backward()
+    _close(ld.grad[:, :sum(n_class)], lr.grad[:, :sum(n_class)], what="dlogits")
+    assert ld.grad[:, sum(n_class):].abs().sum().item() == 0
+    res = ops.heads_forward(logits.to(cuda), n_class, want_argmax=True, want_pmax=True, want_probs=True)
+    o = 0
+    for i, n in enumerate(n_class):
+        p = torch.softmax(logits[:, o:o + n], -1)
+        assert torch.equal(res["argmax"][:, i].cpu(), p.argmax(-1))
+        _close(res["pmax"][:, i], p.max(-1).values, tol=1e-6, what="pmax")
+        _close(res["probs"][:, o:o + n], p, tol=1e-6, what="probs")
+        o += n
+
+
+def test_heads_argmax_tie_picks_lowest_index(cuda):
+    logits = torch.zeros(4, 64)
+    logits[1, 5] = logits[1, 9] = 2.0
+    logits[2, 63] = 1.0
+    res = ops.heads_forward(logits.to(cuda), (64,), want_argmax=True)
+    assert res["argmax"][:, 0].tolist() == [0, 5, 63, 0]
+
+
+def test_heads_bf16_logits(cuda):
+    n_class = (56, 135, 18, 87, 18, 25)
+    rows = 200
+    logits = (torch.randn(rows, 384) * 2).bfloat16()
+    target = torch.stack([torch.randint(0, n, (rows,)) for n in n_class], -1)
+    mask = torch.ones(rows)
+    ref, o = [], 0
+    for i, n in enumerate(n_class):
+        ref.append(F.cross_entropy(logits[:, o:o + n].double(), target[:, i]))
+        o += n
+    out = ops.heads_ce(logits.to(cuda), target.to(cuda), mask.to(cuda), n_class)
+    _close(out, torch.stack(ref), tol=1e-5, what="bf16 losses")
