@@ -1,0 +1,78 @@
+"""Drop-in for /root/reference/ppo_policy/model.py: `Actor_Transformer`, `Critic_Transformer`,
+`LongFormer` (reward model), samplers, `network_paras` -- on the MI355X-native trunk.
+
+Run with this directory as the working directory: `from model import Actor_Transformer, ...`.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+import rlmg_amd  # noqa: E402,F401
+from rlmg_amd.cw_transformer import ATTRS, CWTrunk, Embeddings, PositionalEncoding  # noqa: E402,F401
+from rlmg_amd.sampling import nucleus, sampling, softmax_with_temperature, weighted_sampling  # noqa: E402,F401
+
+try:
+    from config import ActorConfig, DiscriConfig
+except ImportError:
+    from .config import ActorConfig, DiscriConfig
+
+
+def network_paras(model):
+    return sum(int(np.prod(p.size())) for p in model.parameters() if p.requires_grad)
+
+
+class Actor_Transformer(CWTrunk):
+    """ppo_policy/model.py:98-280: the CW trunk + `value_funtion` MLP (512 -> 128 -> 1)."""
+
+    def __init__(self, n_token, is_training=True):
+        super().__init__(n_token, ActorConfig["D_MODEL"], ActorConfig["N_LAYER"], ActorConfig["N_HEAD"],
+                         d_inner=2048, dropout=0.1, is_training=is_training)
+        self.loss_func = nn.CrossEntropyLoss(reduction="none")
+        print("Token_class >>>>>:", self.n_token)
+        if not is_training:
+            print(" [o] using RNN backend.")
+        self.value_funtion = nn.Sequential(nn.Linear(self.d_model, 128), nn.ReLU(), nn.Linear(128, 1))
+        self._declare_heads()
+
+    def forward_output(self, h):
+        return self.split_logits(self.fused_logits(h), h.shape[:-1])
+
+    def forward_output_sampling(self, h):
+        y = [t.float() for t in self.forward_output(h)]
+        return np.array([
+            sampling(y[0], t=1.2, p=0.9), sampling(y[1], p=0.99), sampling(y[2], t=1.2),
+            sampling(y[3], p=0.9), sampling(y[4], t=2, p=0.9), sampling(y[5], t=5),
+        ])
+
+
+class Critic_Transformer(CWTrunk):
+    """ppo_policy/model.py:285-394: trunk + 6 heads + 6 `*_value` Linear(n_f -> 1); value =
+    mean over the sequence, mean over the 6 attributes."""
+
+    def __init__(self, n_token):
+        super().__init__(n_token, ActorConfig["D_MODEL"], ActorConfig["N_LAYER"], ActorConfig["N_HEAD"],
+                         d_inner=2048, dropout=0.1, is_training=True)
+        self.loss_func = nn.CrossEntropyLoss(reduction="none")
+        self._declare_heads()
+        for name, n in zip(ATTRS, self.n_token):
+            setattr(self, name + "_value", nn.Linear(n, 1))
+
+    def value_produce(self, x):
+        """(B, T, 6) -> (B, 1).  Linear(n_f -> 1) after Linear(512 -> n_f) and the mean over T commute
+        with each other, so the value is one (sum n_f)-wide dot per batch row of the T-mean logits."""
+        h = self.forward_hidden(x)
+        B, T = h.shape[0], h.shape[1]
+        logits = self.fused_logits(h).float().view(B, T, -1).mean(dim=1)          # (B, W)
+        total = 0
+        o = 0
+        for name, n in zip(ATTRS, self.n_token):
+            head = getattr(self, name + "_value")
+            total = total + torch.nn.functional.linear(logits[:, o:o + n], head.weight, head.bias)
+            o += n
+        return total / len(self.n_token)

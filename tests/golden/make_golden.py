@@ -1,0 +1,144 @@
+"""Generate the golden fixtures under tests/golden/ by running the REFERENCE's own classes.
+
+Run in the build container only (needs /root/reference, which never travels to the GPU box):
+    python tests/golden/make_golden.py
+
+What runs: /root/reference/dqn_policy/model.py::LinearTransformer and
+/root/reference/ppo_policy/model.py::{Actor_Transformer, Critic_Transformer}, imported unmodified
+from their own directory.  Their top-level `from fast_transformers...` imports are satisfied by
+oracle/ft_standin (a build-owned stand-in backed by oracle/ft_encoder.py), because the real
+package (pytorch-fast-transformers==0.4.0) is a third-party dependency that is absent from the
+reference checkout and from this image.  So these fixtures pin the reference's OWN code
+(embeddings, in_linear, positional encoding, heads, CE loss, value heads) and are "parity unpinned"
+for the encoder body, which comes from the oracle restatement.
+
+To keep the fixtures small the reference classes are instantiated with their config dicts patched
+to a small network (D_MODEL 128, N_LAYER 2, N_HEAD 2 -- BASELINE.json configs[0] dims); one fixture
+uses the repo dims (512/12/8) with T=8 and stores outputs only.
+
+Weights are not stored: tests/golden/fill.py overwrites every parameter with a deterministic
+name-keyed fill, applied identically here (to the reference's modules) and in the tests.
+Fixture = inputs + the reference's outputs / gradient slices (data only).
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+from fill import fill_params  # noqa: E402
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def _import_reference(subdir):
+    from oracle import ft_standin
+    ft_standin.install()
+    for m in ("model", "config"):
+        sys.modules.pop(m, None)
+    path = os.path.join(REF, subdir)
+    sys.path.insert(0, path)
+    try:
+        config = importlib.import_module("config")
+        model = importlib.import_module("model")
+    finally:
+        sys.path.remove(path)
+    return config, model
+
+
+def _np(sd):
+    return {k: v.detach().cpu().numpy() for k, v in sd.items() if k != "pos_emb.pe"}
+
+
+def _tokens(gen, shape, n_class):
+    return torch.stack([torch.randint(0, n, shape, generator=gen) for n in n_class], -1)
+
+
+def dqn_small():
+    config, model = _import_reference("dqn_policy")
+    config.AgentConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    n_class = [56, 135, 18, 87, 18, 25]            # IRL_dqn_train.py:403
+    net = fill_params(model.LinearTransformer(n_class), seed=11).eval()
+    gen = torch.Generator().manual_seed(1234)
+    x, y = _tokens(gen, (2, 16), n_class), _tokens(gen, (2, 16), n_class)
+    mask = torch.ones(2, 16)
+    mask[1, 12:] = 0
+    h = net.forward_hidden(x)
+    logits = net.forward_output(h, y)
+    losses = net.train_step(x, y, mask)
+    loss = sum(losses) / 6
+    net.zero_grad()
+    loss.backward()
+    out = {"x": x.numpy(), "y": y.numpy(), "mask": mask.numpy(), "h": h.detach().numpy(),
+           "losses": np.array([l.item() for l in losses], dtype=np.float64),
+           "grad.in_linear.weight": net.in_linear.weight.grad[:16, ::19].numpy(),
+           "grad.q0": net.transformer_encoder.layers[0].attention.query_projection.weight.grad[::8, ::8].numpy(),
+           "grad.k1": net.transformer_encoder.layers[1].attention.key_projection.weight.grad[::8, ::8].numpy(),
+           "grad.lin1": net.transformer_encoder.layers[1].linear1.weight.grad[::64, ::8].numpy(),
+           "grad.norm1": net.transformer_encoder.layers[0].norm1.weight.grad.numpy(),
+           "grad.emb_pitch": net.word_emb_pitch.lut.weight.grad[:, ::16].numpy(),
+           "grad.proj_chord.bias": net.proj_chord.bias.grad.numpy(),
+           "n_class": np.array(n_class)}
+    for i, l in enumerate(logits):
+        out["logits%d" % i] = l.detach().numpy()
+    out["keys"] = np.array(sorted(net.state_dict().keys()))
+    np.savez_compressed(os.path.join(HERE, "dqn_small.npz"), **out)
+    config.AgentConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
+    return net
+
+
+def dqn_repo_dims():
+    """Repo dims (512/12/8), short T."""
+    config, model = _import_reference("dqn_policy")
+    n_class = [56, 135, 18, 87, 18, 25]
+    net = fill_params(model.LinearTransformer(n_class), seed=12).eval()
+    gen = torch.Generator().manual_seed(99)
+    x = _tokens(gen, (1, 8), n_class)
+    with torch.no_grad():
+        h = net.forward_hidden(x)
+        logits = net.forward_output(h, None)
+    out = {"x": x.numpy(), "h": h.numpy(), "n_params": np.array(model.network_paras(net)),
+           "keys": np.array(sorted(net.state_dict().keys()))}
+    for i, l in enumerate(logits):
+        out["logits%d" % i] = l.numpy()
+    np.savez_compressed(os.path.join(HERE, "dqn_repo_dims.npz"), **out)
+
+
+def ppo_small():
+    config, model = _import_reference("ppo_policy")
+    config.ActorConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    n_token = [49, 19, 19, 89, 67, 25]             # ppo_policy/prepare_data.py:247-291
+    actor = fill_params(model.Actor_Transformer(n_token), seed=21).eval()
+    critic = fill_params(model.Critic_Transformer(n_token), seed=22).eval()
+    gen = torch.Generator().manual_seed(4321)
+    x, y = _tokens(gen, (3, 50), n_token), _tokens(gen, (3, 50), n_token)
+    mask = torch.ones(3, 50, dtype=torch.long)       # ppo passes an int64 mask (ppo_train.py:207,398)
+    with torch.no_grad():
+        h = actor.forward_hidden(x)
+        logits = actor.forward_output(h)
+        value_fn = actor.value_funtion(h[0])
+        losses = actor.train_step(x, y, mask)
+        v = critic.value_produce(x)
+    out = {"x": x.numpy(), "y": y.numpy(), "mask": mask.numpy(), "h": h.numpy(), "value_funtion": value_fn.numpy(),
+           "losses": np.array([l.item() for l in losses], dtype=np.float64), "critic_value": v.numpy(),
+           "n_token": np.array(n_token),
+           "actor_keys": np.array(sorted(actor.state_dict().keys())),
+           "critic_keys": np.array(sorted(critic.state_dict().keys()))}
+    for i, l in enumerate(logits):
+        out["logits%d" % i] = l.numpy()
+    np.savez_compressed(os.path.join(HERE, "ppo_small.npz"), **out)
+    config.ActorConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(4)
+    dqn_small()
+    dqn_repo_dims()
+    ppo_small()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
