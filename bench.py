@@ -1,0 +1,233 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: agent pretrain step of the CW Linear Transformer at repo dims.
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload = BASELINE.json configs[1]: full agent pretrain (d_model 512, 12 layers, 8 heads, d_ff 2048;
+dqn vocabulary [56,135,18,87,18,25]) on synthetic (B, T=1024, 7-field) compound-word sequences,
+bf16 activations / MFMA GEMMs, f32 scan state + statistics + master weights, dropout 0.1 live.
+One step = forward + backward + (DP gradient all-reduce) + clip_grad_norm_(3) + Adam, i.e. the body of
+the reference's loop at dqn_policy/agent_pretrain.py:546-565 -- inputs already resident in HBM.
+Prints ONE JSON line (rank 0).  `value` = CW tokens/s of the whole job.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+N_CLASS_DISK = [56, 135, 18, 3, 87, 18, 25]      # 7 on-disk fields incl. `type` (dropped: agent_pretrain.py:524-526)
+HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+MFMA_BF16_PEAK = 2.5e15                          # dense bf16
+FLOP_PER_TOKEN = 236e6                           # fwd+bwd, repo dims
+
+
+def synth_batch(B, T, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    full = torch.stack([torch.randint(0, n, (2, B, T), generator=g) for n in N_CLASS_DISK], -1)   # (2,B,T,7)
+    keep = [0, 1, 2, 4, 5, 6]
+    x, y = full[0][..., keep].contiguous(), full[1][..., keep].contiguous()
+    mask = torch.ones(B, T)
+    mask[: B // 2, int(T * 0.9):] = 0.0            # last 10 % masked for half the rows
+    return x.to(device), y.to(device), mask.to(device)
+
+
+def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
+    """Algorithmic HBM bytes of ONE launch of a libcwlt entry point at this workload.
+    s = bytes per activation element."""
+    R = B * T
+    return {
+        "cwlt_causal_linear_fwd": R * (4 * D * s + H * 4),
+        "cwlt_causal_linear_bwd_dkdv": R * (6 * D * s + H * 4),
+        "cwlt_causal_linear_bwd_dq": R * (5 * D * s + H * 4),
+        "cwlt_add_dropout_layernorm_fwd": R * (4 * D * s + 8),
+        "cwlt_add_dropout_layernorm_bwd": R * (5 * D * s + 8),
+        "cwlt_bias_gelu_dropout_fwd": R * 2 * F * s,
+        "cwlt_bias_gelu_dropout_bwd": R * 3 * F * s,
+        "cwlt_colsum": R * 3 * D * s,
+        "cwlt_posenc_dropout": R * 2 * D * s,
+        "cwlt_cw_embed_fwd": R * (48 + ncat * s),
+        "cwlt_cw_embed_bwd": R * (48 + ncat * s),
+        "cwlt_heads_fwd": R * (W * s + 48 + 4),
+        "cwlt_heads_ce_bwd": R * (2 * W * s + 48 + 4),
+    }.get(entry)
+
+
+def usable_cores():
+    """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, 64))
+
+
+def log(msg):
+    print("[bench] " + msg, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(seconds_budget=30.0):
+    """The oracle (CPU restatement of the reference path, fp32, all host cores) on a bounded sample:
+    B=1, T=1024 pretrain steps (fwd + bwd + clip + Adam, dropout live)."""
+    from oracle import cw_model
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log("cpu baseline on %d threads ..." % cores)
+    torch.manual_seed(0)
+    net = cw_model.CWLinearTransformer([56, 135, 18, 87, 18, 25], 512, 12, 8, variant="dqn").train()
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    x, y, mask = synth_batch(1, 1024, 1234, "cpu")
+
+    def step():
+        losses = net.train_step(x, y, mask)
+        loss = sum(losses) / 6
+        net.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(net.parameters(), 3)
+        opt.step()
+
+    tw = time.perf_counter()
+    step()                                            # warm-up (allocator, thread pool)
+    log("cpu baseline warm-up step %.1f s" % (time.perf_counter() - tw))
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (time.perf_counter() - t0 < seconds_budget * 0.5 and n < 8):
+        step()
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(1024 / dt, 2), "unit": "CW-tokens/s", "cores": cores, "kind": "port",
+            "sample": "%d steps of B=1 x T=1024 (fwd+bwd+clip+Adam, fp32, dropout 0.1), oracle/cw_model.py" % n}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--seq", type=int, default=1024)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import rlmg_amd  # noqa: F401
+    from rlmg_amd import dist as rdist, ops
+    from rlmg_amd.dqn_policy import model
+
+    rank, local, world = rdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run)" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the cwlt hot path has no CPU implementation")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    torch.manual_seed(0)                               # identical replicas on every rank
+    n_class = [56, 135, 18, 87, 18, 25]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = model.LinearTransformer(n_class)
+    net = net.to(dev).train()
+    net.compute_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    sync = rdist.GradSync(net.parameters())
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4, fused=True)
+    B, T = args.batch, args.seq
+    x, y, mask = synth_batch(B, T, 1234 + rank, dev)   # weak scaling: B sequences per GPU, distinct per rank
+    torch.manual_seed(100 + rank)                      # dropout streams differ per rank
+
+    def step():
+        sync.zero_grad()
+        losses = net.train_step(x, y, mask)
+        loss = (losses[0] + losses[1] + losses[2] + losses[3] + losses[4] + losses[5]) / 6
+        loss.backward()
+        sync.finish()
+        sync.clip_grad_norm_(3.0)
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
+    fence()
+    log("warm-up done, timing %d steps" % args.steps)
+    ops.KernelTimer.reset(rank == 0 and not args.no_kernel_timer)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    ops.KernelTimer.enabled = False
+    log("timed region %.3f s" % dt)
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+    ms_per_step = 1e3 * dt / args.steps
+    tokens_per_s = world * B * T * args.steps / dt
+
+    if rank == 0:
+        s = 2 if args.dtype == "bf16" else 4
+        kt = ops.KernelTimer.summary()
+        roofline = None
+        kernels = {}
+        if kt:
+            tot = {k: c * m for k, (c, m) in kt.items()}
+            for k, (c, m) in sorted(kt.items(), key=lambda kv: -tot[kv[0]]):
+                ab = algorithmic_bytes(k, B, T, s=s)
+                kernels[k] = {"calls_per_step": c / args.steps, "avg_ms": round(m, 4),
+                              "share_of_step": round(tot[k] / (dt * 1e3), 4),
+                              "GB/s": round(ab / (m * 1e-3) / 1e9, 1) if ab else None}
+            dom = max(tot, key=tot.get)
+            ab = algorithmic_bytes(dom, B, T, s=s)
+            ach = ab / (kt[dom][1] * 1e-3) / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if tj.get("batch") == B and tj.get("seq") == T and tj.get("dtype") == args.dtype:
+                    traffic = tj.get("per_launch_bytes", {}).get(dom)
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(kt[dom][1], 4)}
+        out = {
+            "metric": "CW-tokens/sec pretrain fwd+bwd @T=1024", "value": round(tokens_per_s, 1), "unit": "CW-tokens/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "agent_pretrain step (fwd+bwd+clip+Adam), repo dims 512/12/8/2048, "
+                                   "synthetic CW tokens (B=%d/GPU, T=%d, 7 fields -> 6)" % (B, T),
+                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
+                       "parallelism": "dp%d" % world, "dropout": 0.1, "params": 38982227},
+            "final_loss": round(float(loss.item()), 4),
+            "model_mfma_frac": round(tokens_per_s / world * FLOP_PER_TOKEN / MFMA_BF16_PEAK, 4),
+            "roofline": roofline, "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb = cpu_baseline()
+            out["cpu_baseline"] = cb
+            out["gpu_over_cpu"] = round(tokens_per_s / cb["value"], 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,19 @@ int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const vo
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                            int64_t lddq, int64_t lddk, int64_t lddv, int dtype, void* stream);
 
+/* The two kernels of the backward, separately launchable (the call above = dkdv then dq):
+ * reverse scan producing dk, dv; forward scan producing dq. */
+int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, const void* out,
+                                const float* zinv, const void* dout, void* dk, void* dv,
+                                int N, int H, int L, int head_dim,
+                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                                int64_t lddk, int64_t lddv, int dtype, void* stream);
+int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const void* out,
+                              const float* zinv, const void* dout, void* dq,
+                              int N, int H, int L, int head_dim,
+                              int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                              int64_t lddq, int dtype, void* stream);
+
 /* ---- fused residual + dropout + LayerNorm ------------------------------------------------------
  * s = x + dropout_p(a) ; y = LayerNorm(s) * gamma + beta.  Replaces, inside fast_transformers'
  * TransformerEncoderLayer.forward (built at dqn_policy/model.py:128-137, called :232):

@@ -68,9 +68,32 @@ def cla_recurrent(q, k, v, eps=EPS):
     return torch.stack(outs, 1)
 
 
+def cla_chunked(q, k, v, eps=EPS, chunk=64):
+    """Linear-cost form: quadratic inside chunks of `chunk` tokens, running (E x M) state between
+    chunks -- what a CPU implementation of causal_dot_product amounts to, BLAS-friendly."""
+    Q, K = feature_map(q), feature_map(k)
+    N, L, H, E = Q.shape
+    M = v.shape[-1]
+    S = q.new_zeros((N, H, E, M))
+    z = q.new_zeros((N, H, E))
+    outs = []
+    for c0 in range(0, L, chunk):
+        Qc, Kc, Vc = Q[:, c0:c0 + chunk], K[:, c0:c0 + chunk], v[:, c0:c0 + chunk]
+        C = Qc.shape[1]
+        A = torch.einsum("nlhe,nshe->nhls", Qc, Kc) * torch.tril(torch.ones(C, C, dtype=q.dtype, device=q.device))
+        num = torch.einsum("nhls,nshm->nlhm", A, Vc) + torch.einsum("nlhe,nhem->nlhm", Qc, S)
+        den = A.sum(-1).permute(0, 2, 1) + torch.einsum("nlhe,nhe->nlh", Qc, z) + eps
+        outs.append(num / den[..., None])
+        S = S + torch.einsum("nshe,nshm->nhem", Kc, Vc)
+        z = z + Kc.sum(1)
+    return torch.cat(outs, 1)
+
+
 def cla_reference(q, k, v, eps=EPS):
-    """Default oracle form (memory-light, any L)."""
-    return cla_quadratic(q, k, v, eps)
+    """Default oracle form: quadratic for short sequences, chunked (same arithmetic, linear cost) beyond."""
+    if q.shape[1] <= 256:
+        return cla_quadratic(q, k, v, eps)
+    return cla_chunked(q, k, v, eps)
 
 
 def cla_grads(q, k, v, dout, fn=cla_quadratic, eps=EPS):

@@ -25,6 +25,8 @@ _SIGNATURES = {
     "cwlt_causal_linear_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr],
     "cwlt_causal_linear_bwd": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
+    "cwlt_causal_linear_bwd_dkdv": [_ptr] * 8 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr],
+    "cwlt_causal_linear_bwd_dq": [_ptr] * 7 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr],
     "cwlt_ln_blocks": [_c_i64],
     "cwlt_add_dropout_layernorm_fwd": [_ptr] * 8 + [_c_i64, _c_int, _c_f32, _c_f32, _c_u64, _c_int, _ptr],
     "cwlt_add_dropout_layernorm_bwd": [_ptr] * 12 + [_c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],
@@ -54,6 +56,14 @@ def load():
         raise ImportError(
             "libcwlt.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    # Bind libcwlt's hip* symbols to the HIP runtime PyTorch uses (its bundled libamdhip64.so), so
+    # torch streams / device pointers are valid inside the kernels' launches: load that runtime into
+    # the global symbol scope BEFORE libcwlt.so (which carries no DT_NEEDED on a runtime of its own).
+    import torch
+    rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if not os.path.exists(rt):
+        raise ImportError("PyTorch-ROCm's HIP runtime not found at %s" % rt)
+    ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale

@@ -51,7 +51,11 @@ def build(force=False, verbose=False):
         with ThreadPoolExecutor(max_workers=min(4, len(jobs))) as ex:
             list(ex.map(run, jobs))
     if jobs or force or _stale(LIB, objs):
-        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+        # -no-hip-rt: do NOT record a DT_NEEDED on /opt/rocm's libamdhip64.so.7.  PyTorch ships its own HIP
+        # runtime (torch/lib/libamdhip64.so); two runtimes in one process do not share streams or
+        # allocations.  The hip* symbols are bound at load time to the runtime already in the process
+        # (_lib.load() puts torch's in the global scope first; a C host links libamdhip64 itself).
+        run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-no-hip-rt", "-o", LIB] + objs)
     return LIB
 
 

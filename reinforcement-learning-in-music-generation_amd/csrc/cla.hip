@@ -473,15 +473,19 @@ static int launch_fwd(const void* q, const void* k, const void* v, void* out, fl
 }
 
 template <typename T>
-static int launch_bwd(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                      const void* dout, void* dq, void* dk, void* dv, int N, int H, int L, long ldq, long ldk,
-                      long ldv, long ldo, long lddo, long lddq, long lddk, long lddv, hipStream_t st) {
-    // heavier reverse-scan kernel first; the dq kernel back-fills its tail
+static int launch_bwd_dkdv(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                           const void* dout, void* dk, void* dv, int N, int H, int L, long ldq, long ldk, long ldv,
+                           long ldo, long lddo, long lddk, long lddv, hipStream_t st) {
     hipLaunchKernelGGL((cla_bwd_dkdv_kernel<T>), dim3(N * H), dim3(256), 0, st, (const T*)q, (const T*)k,
                        (const T*)v, (const T*)out, (const T*)dout, zinv, (T*)dk, (T*)dv, H, L, ldq, ldk, ldv, ldo,
                        lddo, lddk, lddv);
-    int e = (int)hipGetLastError();
-    if (e) return e;
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int launch_bwd_dq(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                         const void* dout, void* dq, int N, int H, int L, long ldq, long ldk, long ldv, long ldo,
+                         long lddo, long lddq, hipStream_t st) {
     hipLaunchKernelGGL((cla_bwd_dq_kernel<T>), dim3(N * H), dim3(128), 0, st, (const T*)q, (const T*)k, (const T*)v,
                        (const T*)out, (const T*)dout, zinv, (T*)dq, H, L, ldq, ldk, ldv, ldo, lddo, lddq);
     return (int)hipGetLastError();
@@ -507,25 +511,55 @@ int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* ou
     return CWLT_ERR_DTYPE;
 }
 
-int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                           const void* dout, void* dq, void* dk, void* dv, int N, int H, int L, int head_dim,
-                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
-                           int64_t lddk, int64_t lddv, int dtype, void* stream) {
+int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                                const void* dout, void* dk, void* dv, int N, int H, int L, int head_dim,
+                                int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddk,
+                                int64_t lddv, int dtype, void* stream) {
     using namespace cwlt;
-    if (!q || !k || !v || !out || !zinv || !dout || !dq || !dk || !dv) return CWLT_ERR_ARG;
+    if (!q || !k || !v || !out || !zinv || !dout || !dk || !dv) return CWLT_ERR_ARG;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
     if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H) || bad_ld(lddo, H) ||
-        bad_ld(lddq, H) || bad_ld(lddk, H) || bad_ld(lddv, H))
+        bad_ld(lddk, H) || bad_ld(lddv, H))
         return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
-        return launch_bwd<float>(q, k, v, out, zinv, dout, dq, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq,
-                                 lddk, lddv, st);
+        return launch_bwd_dkdv<float>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv,
+                                      st);
     if (dtype == CWLT_BF16)
-        return launch_bwd<bf16_t>(q, k, v, out, zinv, dout, dq, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq,
-                                  lddk, lddv, st);
+        return launch_bwd_dkdv<bf16_t>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk,
+                                       lddv, st);
     return CWLT_ERR_DTYPE;
+}
+
+int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                              const void* dout, void* dq, int N, int H, int L, int head_dim, int64_t ldq,
+                              int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int dtype,
+                              void* stream) {
+    using namespace cwlt;
+    if (!q || !k || !v || !out || !zinv || !dout || !dq) return CWLT_ERR_ARG;
+    if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
+    if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H) || bad_ld(lddo, H) || bad_ld(lddq, H))
+        return CWLT_ERR_ARG;
+    if (N == 0 || L == 0) return CWLT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (dtype == CWLT_F32)
+        return launch_bwd_dq<float>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
+    if (dtype == CWLT_BF16)
+        return launch_bwd_dq<bf16_t>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
+    return CWLT_ERR_DTYPE;
+}
+
+/* both halves of the backward: the heavier reverse scan first, the dq scan back-fills its tail */
+int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                           const void* dout, void* dq, void* dk, void* dv, int N, int H, int L, int head_dim,
+                           int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                           int64_t lddk, int64_t lddv, int dtype, void* stream) {
+    int e = cwlt_causal_linear_bwd_dkdv(q, k, v, out, zinv, dout, dk, dv, N, H, L, head_dim, ldq, ldk, ldv, ldo, lddo,
+                                        lddk, lddv, dtype, stream);
+    if (e) return e;
+    return cwlt_causal_linear_bwd_dq(q, k, v, out, zinv, dout, dq, N, H, L, head_dim, ldq, ldk, ldv, ldo, lddo, lddq,
+                                     dtype, stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,111 @@
+"""Data-parallel gradient exchange: one process per GPU, RCCL (torch.distributed backend "nccl")
+over xGMI.  New functionality relative to the reference, which is single-GPU only.
+
+Gradients live in a few flat f32 buckets (parameter .grad tensors are views into them), filled in
+reverse registration order so the buckets complete in the order backward produces them.  A bucket's
+all-reduce is launched asynchronously the moment its last gradient has been accumulated, so the
+exchange of layer i overlaps the backward of layers < i; xGMI is point-to-point, so a few large
+buckets (default 32 MiB) beat many small ones.  With world_size == 1 the same flat buffers serve the
+fused gradient-norm clip, and nothing is communicated.
+"""
+import torch
+import torch.distributed as dist
+
+
+class _Bucket:
+    __slots__ = ("flat", "params", "pending", "work")
+
+    def __init__(self, flat, params):
+        self.flat, self.params = flat, params
+        self.pending, self.work = len(params), None
+
+
+class GradSync:
+    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+        params = [p for p in params if p.requires_grad]
+        if not params:
+            raise ValueError("no trainable parameters")
+        self.buckets = []
+        cur, cur_n = [], 0
+        for p in reversed(params):
+            cur.append(p)
+            cur_n += p.numel()
+            if cur_n * 4 >= bucket_bytes:
+                self._close(cur)
+                cur, cur_n = [], 0
+        if cur:
+            self._close(cur)
+        self._by_param = {}
+        for b in self.buckets:
+            for p in b.params:
+                self._by_param[p] = b
+                p.register_post_accumulate_grad_hook(self._on_grad)
+
+    def _close(self, params):
+        n = sum(p.numel() for p in params)
+        flat = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+        o = 0
+        for p in params:
+            p.grad = flat[o:o + p.numel()].view_as(p)
+            o += p.numel()
+        self.buckets.append(_Bucket(flat, list(params)))
+
+    def _launch(self, b):
+        if self.world > 1:
+            b.flat.div_(self.world)
+            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+    def _on_grad(self, p):
+        b = self._by_param[p]
+        b.pending -= 1
+        if b.pending == 0:
+            self._launch(b)
+
+    def zero_grad(self):
+        """Replaces net.zero_grad(): keeps the .grad views, zeroes the flat storage."""
+        for b in self.buckets:
+            b.flat.zero_()
+            b.pending, b.work = len(b.params), None
+            o = 0
+            for p in b.params:       # re-attach in case an optimizer / user dropped the view
+                if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + 4 * o:
+                    p.grad = b.flat[o:o + p.numel()].view_as(p)
+                o += p.numel()
+
+    def finish(self):
+        """Wait for every bucket (launching those whose parameters never received a gradient)."""
+        for b in self.buckets:
+            if b.work is None and b.pending > 0:
+                self._launch(b)
+        for b in self.buckets:
+            if b.work is not None:
+                b.work.wait()
+                b.work = None
+
+    def grad_norm(self):
+        return torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(b.flat) for b in self.buckets]))
+
+    def clip_grad_norm_(self, max_norm):
+        """clip_grad_norm_(parameters, max_norm) on the flat buckets (dqn_policy/agent_pretrain.py:563-564)."""
+        total = self.grad_norm()
+        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+        for b in self.buckets:
+            b.flat.mul_(coef)
+        return total
+
+
+def init_from_env():
+    """(rank, local_rank, world) from torchrun's env; initialises RCCL when world > 1."""
+    import os
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local, world

@@ -43,6 +43,42 @@ def _f32(t):
     return t
 
 
+class KernelTimer:
+    """Optional per-launch timing with HIP events on the launch stream (torch's current stream).
+
+    bench.py switches it on for the timed region; each C-ABI call is then bracketed by two events.
+    `summary()` (after a device sync) -> {entry point: (calls, mean ms)}."""
+    enabled = False
+    records = {}
+
+    @classmethod
+    def reset(cls, enabled):
+        cls.enabled = bool(enabled)
+        cls.records = {}
+
+    @classmethod
+    def summary(cls):
+        out = {}
+        for name, evs in cls.records.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = (len(ms), sum(ms) / max(1, len(ms)))
+        return out
+
+
+def _call(name, *args):
+    """Invoke one libcwlt entry point on the current stream and raise on a non-zero status."""
+    fn = getattr(_lib.load(), name)
+    if KernelTimer.enabled:
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        st = fn(*args)
+        b.record()
+        KernelTimer.records.setdefault(name, []).append((a, b))
+    else:
+        st = fn(*args)
+    _lib.check(st, name)
+
+
 _seed_counter = [0]
 
 
@@ -68,10 +104,8 @@ def cla_fwd(q, k, v, eps=CLA_EPS):
     v, ldv = _as_rows(v)
     out = torch.empty((N, L, H, D), dtype=q.dtype, device=q.device)
     zinv = torch.empty((N, L, H), dtype=torch.float32, device=q.device)
-    _lib.check(lib.cwlt_causal_linear_fwd(
-        _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.dev(out), _lib.dev(zinv),
-        N, H, L, D, ldq, ldk, ldv, H * D, float(eps), _lib.dtype_code(q.dtype), _lib.stream_ptr()),
-        "cwlt_causal_linear_fwd")
+    _call("cwlt_causal_linear_fwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.dev(out), _lib.dev(zinv),
+        N, H, L, D, ldq, ldk, ldv, H * D, float(eps), _lib.dtype_code(q.dtype), _lib.stream_ptr())
     return q, k, v, out, zinv
 
 
@@ -85,11 +119,12 @@ def cla_bwd(q, k, v, out, zinv, dout):
     v, ldv = _as_rows(v)
     dqkv = torch.empty((N, L, 3, H, D), dtype=q.dtype, device=q.device)
     ld = 3 * H * D
-    _lib.check(lib.cwlt_causal_linear_bwd(
-        _lib.dev(q), _lib.dev(k), _lib.dev(v), _lib.dev(out), _lib.dev(zinv), _lib.dev(dout, "dout"),
-        _lib.dev(dqkv[:, :, 0]), _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]), N, H, L, D,
-        ldq, ldk, ldv, H * D, lddo, ld, ld, ld, _lib.dtype_code(q.dtype), _lib.stream_ptr()),
-        "cwlt_causal_linear_bwd")
+    common = (_lib.dev(q), _lib.dev(k), _lib.dev(v), _lib.dev(out), _lib.dev(zinv), _lib.dev(dout, "dout"))
+    code, st = _lib.dtype_code(q.dtype), _lib.stream_ptr()
+    _call("cwlt_causal_linear_bwd_dkdv", *common, _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]), N, H, L, D,
+          ldq, ldk, ldv, H * D, lddo, ld, ld, code, st)
+    _call("cwlt_causal_linear_bwd_dq", *common, _lib.dev(dqkv[:, :, 0]), N, H, L, D,
+          ldq, ldk, ldv, H * D, lddo, ld, code, st)
     return dqkv
 
 
@@ -132,10 +167,9 @@ def ln_fwd(x, a, gamma, beta, eps=LN_EPS, p=0.0, seed=0, save_s=True):
     s = torch.empty_like(a) if need_s else None
     mean = torch.empty(rows, dtype=torch.float32, device=a.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
-    _lib.check(lib.cwlt_add_dropout_layernorm_fwd(
-        _lib.opt(x), _lib.dev(a, "a"), _lib.dev(gamma), _lib.dev(beta), _lib.opt(s), _lib.dev(y),
+    _call("cwlt_add_dropout_layernorm_fwd", _lib.opt(x), _lib.dev(a, "a"), _lib.dev(gamma), _lib.dev(beta), _lib.opt(s), _lib.dev(y),
         _lib.dev(mean), _lib.dev(rstd), rows, D, float(eps), float(p), int(seed),
-        _lib.dtype_code(a.dtype), _lib.stream_ptr()), "cwlt_add_dropout_layernorm_fwd")
+        _lib.dtype_code(a.dtype), _lib.stream_ptr())
     if save_s and s is None:
         s = a
     return s, y, mean, rstd
@@ -153,11 +187,10 @@ def ln_bwd(dy, dy2, s, gamma, mean, rstd, p=0.0, seed=0, want_dbias=True):
     nb = lib.cwlt_ln_blocks(rows)
     part = torch.empty(nb * 3 * D, dtype=torch.float32, device=s.device)
     stats = torch.empty((3, D), dtype=torch.float32, device=s.device)
-    _lib.check(lib.cwlt_add_dropout_layernorm_bwd(
-        _lib.dev(dy, "dy"), _lib.opt(dy2), _lib.dev(s), _lib.dev(gamma), _lib.dev(mean), _lib.dev(rstd),
+    _call("cwlt_add_dropout_layernorm_bwd", _lib.dev(dy, "dy"), _lib.opt(dy2), _lib.dev(s), _lib.dev(gamma), _lib.dev(mean), _lib.dev(rstd),
         _lib.dev(ds), _lib.dev(da) if p > 0 else None, _lib.dev(part), _lib.dev(stats[0]), _lib.dev(stats[1]),
         _lib.dev(stats[2]) if want_dbias else None, rows, D, float(p), int(seed),
-        _lib.dtype_code(s.dtype), _lib.stream_ptr()), "cwlt_add_dropout_layernorm_bwd")
+        _lib.dtype_code(s.dtype), _lib.stream_ptr())
     return ds, da, stats[0], stats[1], (stats[2] if want_dbias else None)
 
 
@@ -191,9 +224,8 @@ def gelu_fwd(h, bias, p=0.0, seed=0):
     lib = _lib.load()
     rows, F = h.shape
     g = torch.empty_like(h)
-    _lib.check(lib.cwlt_bias_gelu_dropout_fwd(_lib.dev(h, "h"), _lib.opt(bias), _lib.dev(g), rows, F, float(p),
-                                              int(seed), _lib.dtype_code(h.dtype), _lib.stream_ptr()),
-               "cwlt_bias_gelu_dropout_fwd")
+    _call("cwlt_bias_gelu_dropout_fwd", _lib.dev(h, "h"), _lib.opt(bias), _lib.dev(g), rows, F, float(p),
+                                              int(seed), _lib.dtype_code(h.dtype), _lib.stream_ptr())
     return g
 
 
@@ -206,10 +238,9 @@ def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
     if want_dbias:
         part = torch.empty(lib.cwlt_rowslab_blocks(rows) * F, dtype=torch.float32, device=h.device)
         dbias = torch.empty(F, dtype=torch.float32, device=h.device)
-    _lib.check(lib.cwlt_bias_gelu_dropout_bwd(_lib.dev(dg, "dg"), _lib.dev(h), _lib.opt(bias), _lib.dev(dh),
+    _call("cwlt_bias_gelu_dropout_bwd", _lib.dev(dg, "dg"), _lib.dev(h), _lib.opt(bias), _lib.dev(dh),
                                               _lib.opt(part), _lib.opt(dbias), rows, F, float(p), int(seed),
-                                              _lib.dtype_code(h.dtype), _lib.stream_ptr()),
-               "cwlt_bias_gelu_dropout_bwd")
+                                              _lib.dtype_code(h.dtype), _lib.stream_ptr())
     return dh, dbias
 
 
@@ -221,8 +252,8 @@ def colsum(x):
         return x.float().sum(0)
     part = torch.empty(lib.cwlt_colsum_blocks(rows) * ncols, dtype=torch.float32, device=x.device)
     out = torch.empty(ncols, dtype=torch.float32, device=x.device)
-    _lib.check(lib.cwlt_colsum(_lib.dev(x, "x"), _lib.dev(part), _lib.dev(out), rows, ncols, x.stride(0),
-                               _lib.dtype_code(x.dtype), _lib.stream_ptr()), "cwlt_colsum")
+    _call("cwlt_colsum", _lib.dev(x, "x"), _lib.dev(part), _lib.dev(out), rows, ncols, x.stride(0),
+                               _lib.dtype_code(x.dtype), _lib.stream_ptr())
     return out
 
 
@@ -232,9 +263,8 @@ def posenc_dropout(x, pe, T, p=0.0, seed=0):
     rows, D = x.shape
     x = x.contiguous()
     y = torch.empty_like(x)
-    _lib.check(lib.cwlt_posenc_dropout(_lib.dev(x, "x"), _lib.opt(pe), _lib.dev(y), rows, int(T), D, float(p),
-                                       int(seed), _lib.dtype_code(x.dtype), _lib.stream_ptr()),
-               "cwlt_posenc_dropout")
+    _call("cwlt_posenc_dropout", _lib.dev(x, "x"), _lib.opt(pe), _lib.dev(y), rows, int(T), D, float(p),
+                                       int(seed), _lib.dtype_code(x.dtype), _lib.stream_ptr())
     return y
 
 
@@ -278,9 +308,9 @@ class CWEmbedFn(torch.autograd.Function):
         rows = tok.shape[0]
         dcat = sum(widths)
         out = torch.empty((rows, dcat), dtype=out_dtype, device=tok.device)
-        _lib.check(lib.cwlt_cw_embed_fwd(_lib.dev(tok, "tokens"), _lib.ptr_array(tabs), _lib.int_array(widths),
+        _call("cwlt_cw_embed_fwd", _lib.dev(tok, "tokens"), _lib.ptr_array(tabs), _lib.int_array(widths),
                                          _lib.int_array(nrows), A, _lib.dev(out), rows, dcat,
-                                         _lib.dtype_code(out_dtype), _lib.stream_ptr()), "cwlt_cw_embed_fwd")
+                                         _lib.dtype_code(out_dtype), _lib.stream_ptr())
         ctx.save_for_backward(tok)
         ctx.widths, ctx.nrows = widths, nrows
         return out.view(*tokens.shape[:-1], dcat)
@@ -297,9 +327,9 @@ class CWEmbedFn(torch.autograd.Function):
         total = sum(w * n for w, n in zip(widths, nrows))
         part = torch.empty(lib.cwlt_embed_splits(rows) * total, dtype=torch.float32, device=d2.device)
         flat = torch.empty(total, dtype=torch.float32, device=d2.device)
-        _lib.check(lib.cwlt_cw_embed_bwd(_lib.dev(tok), _lib.int_array(widths), _lib.int_array(nrows), A,
+        _call("cwlt_cw_embed_bwd", _lib.dev(tok), _lib.int_array(widths), _lib.int_array(nrows), A,
                                          _lib.dev(d2, "dout"), _lib.dev(part), _lib.dev(flat), rows, dcat,
-                                         _lib.dtype_code(d2.dtype), _lib.stream_ptr()), "cwlt_cw_embed_bwd")
+                                         _lib.dtype_code(d2.dtype), _lib.stream_ptr())
         grads, o = [], 0
         for w, n in zip(widths, nrows):
             grads.append(flat[o:o + w * n].view(n, w))
@@ -332,10 +362,10 @@ def heads_forward(logits, n_class, target=None, mask=None, want_argmax=False, wa
     pm = res["pmax"] = torch.empty((rows, A), dtype=torch.float32, device=dev) if want_pmax else None
     ncol = sum(n_class)
     pr = res["probs"] = torch.empty((rows, ncol), dtype=torch.float32, device=dev) if want_probs else None
-    _lib.check(lib.cwlt_heads_fwd(_lib.dev(logits, "logits"), _lib.int_array(n_class), A, _lib.opt(target),
+    _call("cwlt_heads_fwd", _lib.dev(logits, "logits"), _lib.int_array(n_class), A, _lib.opt(target),
                                   _lib.opt(mask), _lib.opt(loss_part), _lib.opt(loss_sum), _lib.opt(am),
                                   _lib.opt(pm), _lib.opt(pr), rows, ld, ncol, _lib.dtype_code(logits.dtype),
-                                  _lib.stream_ptr()), "cwlt_heads_fwd")
+                                  _lib.stream_ptr())
     return res
 
 
@@ -361,10 +391,9 @@ class HeadsCEFn(torch.autograd.Function):
         n_class = ctx.n_class
         coef = (gloss.float() / msum).contiguous()
         dlogits = torch.empty_like(logits)
-        _lib.check(lib.cwlt_heads_ce_bwd(_lib.dev(logits), _lib.int_array(n_class), len(n_class), _lib.dev(target),
+        _call("cwlt_heads_ce_bwd", _lib.dev(logits), _lib.int_array(n_class), len(n_class), _lib.dev(target),
                                          _lib.dev(mask_f), _lib.dev(coef), _lib.dev(dlogits), logits.shape[0],
-                                         logits.stride(0), _lib.dtype_code(logits.dtype), _lib.stream_ptr()),
-                   "cwlt_heads_ce_bwd")
+                                         logits.stride(0), _lib.dtype_code(logits.dtype), _lib.stream_ptr())
         return dlogits, None, None, None
 
 
