@@ -507,7 +507,11 @@ int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* ou
     if (N == 0 || L == 0) return CWLT_OK;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32) return launch_fwd<float>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
-    if (dtype == CWLT_BF16) return launch_fwd<bf16_t>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
+    if (dtype == CWLT_BF16) {
+        if (((ldq | ldk | ldv | ldo) & 7) == 0)
+            return launch_cla_fwd_bf16(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
+        return launch_fwd<bf16_t>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
+    }
     return CWLT_ERR_DTYPE;
 }
 
@@ -526,9 +530,13 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
     if (dtype == CWLT_F32)
         return launch_bwd_dkdv<float>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv,
                                       st);
-    if (dtype == CWLT_BF16)
+    if (dtype == CWLT_BF16) {
+        if (((ldq | ldk | ldv | ldo | lddo | lddk | lddv) & 7) == 0)
+            return launch_cla_bwd_dkdv_bf16(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk,
+                                            lddv, st);
         return launch_bwd_dkdv<bf16_t>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk,
                                        lddv, st);
+    }
     return CWLT_ERR_DTYPE;
 }
 
@@ -545,8 +553,11 @@ int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
         return launch_bwd_dq<float>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
-    if (dtype == CWLT_BF16)
+    if (dtype == CWLT_BF16) {
+        if (((ldq | ldk | ldv | ldo | lddo | lddq) & 7) == 0)
+            return launch_cla_bwd_dq_bf16(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
         return launch_bwd_dq<bf16_t>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
+    }
     return CWLT_ERR_DTYPE;
 }
 

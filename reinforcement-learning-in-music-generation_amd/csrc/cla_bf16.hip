@@ -1,0 +1,637 @@
+// Causal linear attention, bf16-storage throughput path for gfx950 (forward + backward).
+//
+// Same mathematics and C-ABI as cla.hip (which remains the f32 / parity path); this file is what
+// CWLT_BF16 tensors run through.  Replaces fast_transformers' CausalLinearAttention + causal_dot_product
+// (reference call sites: dqn_policy/model.py:128-137,231-232).
+//
+// Why a second implementation: with bf16 activations the f32 MFMA (64 cycles per 32x32x2) made the
+// scan compute-bound at ~4x its HBM time.  Here every product is v_mfma_f32_32x32x16_bf16 (16x the
+// rate).  Accuracy is kept at the level of the bf16 output rounding:
+//   * running states (64x64 KV state and the reverse states) accumulate in f32 MFMA accumulators for
+//     the whole sequence and are fed back as operands split hi + lo (two bf16 MFMAs, ~16 mantissa bits);
+//   * the intra-chunk score tile is rounded to bf16 once and the SAME rounded tile feeds both the
+//     numerator and the normaliser, so each output row stays an exactly normalised combination;
+//   * forward / dQ outputs leave through an f32 LDS tile and are rounded to bf16 once.
+//
+// Layout: workgroup = 4 waves = one (n, h) stream, chunk = 64 tokens; wave (wi, wj) owns the 32x32
+// tile (wi, wj) of every 64x64 product.  Operand tiles live in LDS ROW-MAJOR only, bf16 [64][72]
+// (144-B rows: conflict-free 16-B row-type fragment reads); operands that must be contracted over
+// the token index are fetched transposed by ds_read_b64_tr_b16.  Every product is evaluated in the
+// orientation whose accumulator layout (rows on registers) lets the tile be written 8-16 B per lane.
+// The normaliser and all rank-1 terms (phi(q).ksum, dden*ksum, r1) ride on the MFMA pipe as a 65th
+// "ones" value column built from constant register fragments -- no cross-lane reductions.
+#include "cwlt_common.h"
+
+namespace cwlt {
+namespace b16 {
+
+constexpr int D = 64;    // head dim
+constexpr int C = 64;    // tokens per chunk
+constexpr int LD = 72;   // bf16 tile row stride (144 B)
+constexpr int LDO = 68;  // f32 output tile row stride (272 B)
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+
+// elu(x)+1 with the hardware exp (v_exp_f32, ~1 ulp): far below bf16 resolution, ~12 VALU
+// instructions per element cheaper than expf -- this path is issue-bound, not HBM-bound.
+__device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
+__device__ __forceinline__ float dphi(float x) { return x > 0.f ? 1.f : __expf(x); }
+__device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
+
+__device__ __forceinline__ f32x16 mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) z[i] = 0.f;
+    return z;
+}
+
+// row-type fragment X[l&31][k .. k+7] = T[row][k..k+7] of a row-major tile (k already includes 8*hf)
+__device__ __forceinline__ bf16x8 row8(const bf16_t* t, int row, int k) {
+    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(t + row * LD + k));
+}
+// row-type fragment in the k order of an accumulator-held partner operand:
+// k = k0 + 4*hf + {0..3} and k0 + 8 + 4*hf + {0..3}
+__device__ __forceinline__ bf16x8 perm8(const bf16_t* t, int row, int k0, int hf) {
+    const uint2 a = *reinterpret_cast<const uint2*>(t + row * LD + k0 + 4 * hf);
+    const uint2 b = *reinterpret_cast<const uint2*>(t + row * LD + k0 + 8 + 4 * hf);
+    return __builtin_bit_cast(bf16x8, make_uint4(a.x, a.y, b.x, b.y));
+}
+// transposed fragment X[l&31][8h + j] = T[k0 + 8h + j][c0 + (l&31)] via ds_read_b64_tr_b16: lane 4q+p
+// of a 16-lane group supplies &T[r0+q][cb+4p] and receives T[r0..r0+3][cb + lane%16]
+// (semantics verified on gfx950 with tools/probes/tr16_probe.hip).
+__device__ __forceinline__ bf16x8 tfrag8(const bf16_t* t, int k0, int c0, int lane) {
+    const int q = (lane >> 2) & 3, p = lane & 3;
+    const bf16_t* base = t + (k0 + 8 * (lane >> 5) + q) * LD + c0 + 16 * ((lane >> 4) & 1) + 4 * p;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * LD));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+// accumulator registers 8s..8s+7 as an operand fragment, split hi + lo
+__device__ __forceinline__ void acc_frag(const f32x16& S, int s, bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = S[8 * s + j];
+        const __bf16 h = (__bf16)x;
+        hi[j] = h;
+        lo[j] = (__bf16)(x - (float)h);
+    }
+}
+// fragment [x, 0, 0, 0, 0, 0, 0, 0] in lane-half 0, zeros in lane-half 1: element (k = 0) of an
+// augmentation k-step when paired with acc_frag(., 0) (whose element 0 of lane-half 0 is row 0)
+__device__ __forceinline__ bf16x8 first_if(bool c, float x) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.0f;
+    v[0] = (__bf16)(c ? x : 0.0f);
+    return v;
+}
+__device__ __forceinline__ bf16x8 ones_if(bool c) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)(c ? 1.0f : 0.0f);
+    return v;
+}
+
+// acc[x][y] += sum_k a_t[arow][k] * b_t[brow][k] over k-steps [s0, s1)
+__device__ __forceinline__ f32x16 prod_rows(f32x16 acc, const bf16_t* a_t, int arow, const bf16_t* b_t, int brow,
+                                            int s0, int s1, int hf) {
+#pragma unroll 2
+    for (int s = s0; s < s1; ++s)
+        acc = mfma(row8(a_t, arow, 16 * s + 8 * hf), row8(b_t, brow, 16 * s + 8 * hf), acc);
+    return acc;
+}
+// Z[n][col] += sum_k X_t[k][n] * b_t[brow][32t + k]: accumulator tiles X0, X1 (rows k on regs) as the
+// A operand, hi + lo; b_t row-type in the permuted k order.  8 MFMAs.
+__device__ __forceinline__ f32x16 prod_accA(f32x16 acc, const f32x16& X0, const f32x16& X1, const bf16_t* b_t,
+                                            int brow, int hf) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const f32x16& X = t == 0 ? X0 : X1;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 hi, lo;
+            acc_frag(X, s, hi, lo);
+            const bf16x8 b = perm8(b_t, brow, 32 * t + 16 * s, hf);
+            acc = mfma(hi, b, acc);
+            acc = mfma(lo, b, acc);
+        }
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void unpack8(uint4 r, float (&x)[8]) {
+    x[0] = __uint_as_float(r.x << 16); x[1] = __uint_as_float(r.x & 0xffff0000u);
+    x[2] = __uint_as_float(r.y << 16); x[3] = __uint_as_float(r.y & 0xffff0000u);
+    x[4] = __uint_as_float(r.z << 16); x[5] = __uint_as_float(r.z & 0xffff0000u);
+    x[6] = __uint_as_float(r.w << 16); x[7] = __uint_as_float(r.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 pack8(const float (&x)[8]) {
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)x[j];
+    return __builtin_bit_cast(uint4, v);
+}
+__device__ __forceinline__ void put_row(bf16_t* t, int row, int col, uint4 v) {
+    *reinterpret_cast<uint4*>(t + row * LD + col) = v;
+}
+// accumulator tile (rows rr on regs, cols on lanes) -> x[xrow = this lane's col][c0 + rr], bf16, 8 B at
+// a time; element kept iff lo <= rr <= hi (rr = row inside the 32-tile), `add` added first
+__device__ __forceinline__ void put_acc_T(bf16_t* x, int xrow, int c0, const f32x16& acc, int hf, int lo, int hi,
+                                          float add) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 p;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr = 8 * g + 4 * hf + u;  // = acc_row(4g+u, hf)
+            p[u] = (__bf16)((rr >= lo && rr <= hi) ? acc[4 * g + u] + add : 0.f);
+        }
+        *reinterpret_cast<uint2*>(x + xrow * LD + c0 + 8 * g + 4 * hf) = __builtin_bit_cast(uint2, p);
+    }
+}
+// same, f32 destination tile (16 B at a time)
+__device__ __forceinline__ void put_acc_T_f32(float* x, int xrow, int c0, const f32x16& acc, int hf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(x + xrow * LDO + c0 + 8 * g + 4 * hf) =
+            make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward.  wave (wi, wj): score tile (i-half wi, j-half wj), numerator tile (i-half wi, m-half wj) and
+// half of the normaliser:  den_i = sum_j A~[i][j] * 1 + phi(q_i) . ksum,  ksum = state of the ones column.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
+                                                           const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
+                                                           float* __restrict__ zinv, int H, int L, long ldq, long ldk,
+                                                           long ldv, long ldo, float eps) {
+    __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // phi(q)  [i][e]
+    __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
+    __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
+    __shared__ __attribute__((aligned(16))) bf16_t as_[C * LD];  // masked scores [i][j]
+    __shared__ __attribute__((aligned(16))) float os[C * LDO];   // un-normalised output tile [i][m]
+    __shared__ float dens[2][C];                                 // normaliser halves
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w >> 1, wj = w & 1;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int n = blockIdx.x / H, h = blockIdx.x % H;
+    const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
+    const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
+    const bf16_t* vb = v + ((long)n * L) * ldv + h * D;
+    bf16_t* ob = o + ((long)n * L) * ldo + h * D;
+    float* zb = zinv + ((long)n * L) * H + h;
+
+    const int srow = tid >> 3, scol = (tid & 7) * 8;
+    const int nch = (L + C - 1) / C;
+    const uint4 u4z = make_uint4(0, 0, 0, 0);
+    uint4 rq[2], rk[2], rv[2];
+    const bf16x8 ones0 = ones_if(l31 == 0);   // A operand: row 0 of the ones block, all k
+
+#define CLA_LOAD(c)                                                                      \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
+        const long row = (long)(c) * C + srow + 32 * it;                                 \
+        const bool ok = row < L;                                                         \
+        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : u4z;      \
+        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : u4z;      \
+        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : u4z;      \
+    }
+#define CLA_STORE(c)                                                                     \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
+        const int row = srow + 32 * it;                                                  \
+        const long grow = (long)(c) * C + row;                                           \
+        if (grow < L) {                                                                  \
+            const float z = 1.0f / (dens[0][row] + dens[1][row] + eps);                  \
+            const float4 a = *reinterpret_cast<const float4*>(os + row * LDO + scol);    \
+            const float4 b = *reinterpret_cast<const float4*>(os + row * LDO + scol + 4);\
+            const float x[8] = {a.x * z, a.y * z, a.z * z, a.w * z, b.x * z, b.y * z, b.z * z, b.w * z}; \
+            *reinterpret_cast<uint4*>(ob + grow * ldo + scol) = pack8(x);                \
+            if ((tid & 7) == 0) zb[grow * H] = z;                                        \
+        }                                                                                \
+    }
+
+    CLA_LOAD(0);
+    f32x16 S0 = zero16(), S1 = zero16();  // S[e-half t][m-half wj]: rows e on regs, cols m on lanes
+    f32x16 Sa = zero16();                 // ones-column state, e-half wj: Sa[e][0] = ksum[32wj + e]
+
+    for (int c = 0; c < nch; ++c) {
+        if (c > 0) { CLA_STORE(c - 1); }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = srow + 32 * it;
+            const bool ok = c * C + row < L;
+            float x[8];
+            unpack8(rq[it], x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+            put_row(qs, row, scol, pack8(x));
+            unpack8(rk[it], x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+            put_row(ks, row, scol, pack8(x));
+            put_row(vs, row, scol, rv[it]);
+        }
+        __syncthreads();
+        if (c + 1 < nch) { CLA_LOAD(c + 1); }
+
+        // scores as A^T (rows j on regs, cols i on lanes) -> as_[i][j], masked j <= i
+        if (!(wi == 0 && wj == 1)) {
+            const f32x16 AT = prod_rows(zero16(), ks, 32 * wj + l31, qs, 32 * wi + l31, 0, 4, hf);
+            put_acc_T(as_, 32 * wi + l31, 32 * wj, AT, hf, 0, wi == wj ? l31 : 64, 0.f);
+        }
+        __syncthreads();
+
+        {
+            // O^T tile (rows m on regs, cols i on lanes) = v^T A~^T + S^T phi(q)^T ; ones row alongside
+            f32x16 O = zero16(), Oa = zero16();
+            const int nks = wi == 0 ? 2 : 4;
+#pragma unroll 2
+            for (int s = 0; s < nks; ++s) {
+                const bf16x8 b = row8(as_, 32 * wi + l31, 16 * s + 8 * hf);
+                O = mfma(tfrag8(vs, 16 * s, 32 * wj, lane), b, O);
+                if (wj == 0) Oa = mfma(ones0, b, Oa);
+            }
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                const f32x16& S = t == 0 ? S0 : S1;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    bf16x8 hi, lo;
+                    acc_frag(S, s, hi, lo);
+                    const bf16x8 b = perm8(qs, 32 * wi + l31, 32 * t + 16 * s, hf);
+                    O = mfma(hi, b, O);
+                    O = mfma(lo, b, O);
+                    if (t == wj) {
+                        acc_frag(Sa, s, hi, lo);
+                        Oa = mfma(hi, b, Oa);
+                        Oa = mfma(lo, b, Oa);
+                    }
+                }
+            }
+            put_acc_T_f32(os, 32 * wi + l31, 32 * wj, O, hf);
+            if (hf == 0) dens[wj][32 * wi + l31] = Oa[0];   // row 0 of the ones block
+        }
+        // states: S_t[e][m] += sum_j phi(k)[j][32t+e] v[j][32wj+m] ;  Sa[e][0] += sum_j phi(k)[j][32wj+e]
+#pragma unroll 2
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 b = tfrag8(vs, 16 * s, 32 * wj, lane);
+            const bf16x8 a0 = tfrag8(ks, 16 * s, 0, lane);
+            const bf16x8 a1 = tfrag8(ks, 16 * s, 32, lane);
+            S0 = mfma(a0, b, S0);
+            S1 = mfma(a1, b, S1);
+            Sa = mfma(wj == 0 ? a0 : a1, ones_if(l31 == 0), Sa);
+        }
+        __syncthreads();
+    }
+    CLA_STORE(nch - 1);
+#undef CLA_LOAD
+#undef CLA_STORE
+}
+
+// Common staging of the backward kernels for one (row, 8-column) slot:
+//   g = dout * z  (bf16),  dden = -(dout . out) * z  (row dot over the 8 threads of the row)
+__device__ __forceinline__ uint4 stage_g(uint4 rdo, uint4 ro, float z, float& dden) {
+    float a[8], b[8];
+    unpack8(rdo, a);
+    unpack8(ro, b);
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        dot = fmaf(a[j], b[j], dot);
+        a[j] *= z;
+    }
+    dot += __shfl_xor(dot, 1, 64);
+    dot += __shfl_xor(dot, 2, 64);
+    dot += __shfl_xor(dot, 4, 64);
+    dden = -dot * z;
+    return pack8(a);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dQ (forward scan).  W_ij = g_i . v_j + dden_i (j <= i)
+//   dqf_i = sum_{j<=i} W_ij kf_j = (W kf)_i + S_prev g_i + dden_i ksum_prev ;  dQ = dqf * phi'(Q)
+// wave (wi, wj): W tile (i-half wi, j-half wj); dq tile (i-half wi, e-half wj).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
+    bf16_t* __restrict__ dq, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq) {
+    __shared__ __attribute__((aligned(16))) bf16_t gs[C * LD];   // g       [i][m]
+    __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
+    __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
+    __shared__ __attribute__((aligned(16))) bf16_t ws[C * LD];   // masked W [i][j]
+    __shared__ __attribute__((aligned(16))) float os[C * LDO];   // dqf tile [i][e]
+    __shared__ float dd[C];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w >> 1, wj = w & 1;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int n = blockIdx.x / H, h = blockIdx.x % H;
+    const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
+    const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
+    const bf16_t* vb = v + ((long)n * L) * ldv + h * D;
+    const bf16_t* ob = out + ((long)n * L) * ldo + h * D;
+    const bf16_t* gb = dout + ((long)n * L) * lddo + h * D;
+    const float* zb = zinv + ((long)n * L) * H + h;
+    bf16_t* dqb = dq + ((long)n * L) * lddq + h * D;
+
+    const int srow = tid >> 3, scol = (tid & 7) * 8;
+    const int nch = (L + C - 1) / C;
+    const uint4 u4z = make_uint4(0, 0, 0, 0);
+    uint4 rq[2], rk[2], rv[2], rg[2], ro[2], rqp[2];
+    float rz[2];
+
+#define CLA_LOAD(c)                                                                      \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
+        const long row = (long)(c) * C + srow + 32 * it;                                 \
+        const bool ok = row < L;                                                         \
+        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : u4z;      \
+        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : u4z;      \
+        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : u4z;      \
+        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : u4z;     \
+        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : u4z;      \
+        rz[it] = ok ? zb[row * H] : 0.f;                                                 \
+    }
+#define CLA_STORE(c)                                                                     \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
+        const int row = srow + 32 * it;                                                  \
+        const long grow = (long)(c) * C + row;                                           \
+        if (grow < L) {                                                                  \
+            const float4 a = *reinterpret_cast<const float4*>(os + row * LDO + scol);    \
+            const float4 b = *reinterpret_cast<const float4*>(os + row * LDO + scol + 4);\
+            float x[8];                                                                  \
+            unpack8(rqp[it], x);                                                         \
+            x[0] = a.x * dphi(x[0]); x[1] = a.y * dphi(x[1]); x[2] = a.z * dphi(x[2]);   \
+            x[3] = a.w * dphi(x[3]); x[4] = b.x * dphi(x[4]); x[5] = b.y * dphi(x[5]);   \
+            x[6] = b.z * dphi(x[6]); x[7] = b.w * dphi(x[7]);                            \
+            *reinterpret_cast<uint4*>(dqb + grow * lddq + scol) = pack8(x);              \
+        }                                                                                \
+    }
+
+    CLA_LOAD(0);
+    f32x16 T0 = zero16(), T1 = zero16();  // ST_t[m][e] = S[32wj+e][32t+m]: rows m on regs, cols e on lanes
+    f32x16 Ta = zero16();                 // ones row: Ta[0][e] = ksum[32wj + e]
+    const bf16x8 ones0 = ones_if(l31 == 0);
+
+    for (int c = 0; c < nch; ++c) {
+        if (c > 0) { CLA_STORE(c - 1); }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = srow + 32 * it;
+            const bool ok = c * C + row < L;
+            float dden;
+            const uint4 gp = stage_g(rg[it], ro[it], rz[it], dden);
+            if ((tid & 7) == 0) dd[row] = dden;
+            put_row(gs, row, scol, gp);
+            put_row(vs, row, scol, rv[it]);
+            float x[8];
+            unpack8(rk[it], x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+            put_row(ks, row, scol, pack8(x));
+            rqp[it] = rq[it];
+        }
+        __syncthreads();
+        if (c + 1 < nch) { CLA_LOAD(c + 1); }
+
+        const float dden_i = dd[32 * wi + l31];
+        // W^T (rows j on regs, cols i on lanes) = v g^T  (+ dden_i) -> ws[i][j], masked j <= i
+        if (!(wi == 0 && wj == 1)) {
+            const f32x16 WT = prod_rows(zero16(), vs, 32 * wj + l31, gs, 32 * wi + l31, 0, 4, hf);
+            put_acc_T(ws, 32 * wi + l31, 32 * wj, WT, hf, 0, wi == wj ? l31 : 64, dden_i);
+        }
+        __syncthreads();
+
+        {
+            // dqf^T tile (rows e on regs, cols i on lanes) = kf^T W^T + ST^T g^T + ksum (x) dden
+            f32x16 Q = zero16();
+            const int nks = wi == 0 ? 2 : 4;
+#pragma unroll 2
+            for (int s = 0; s < nks; ++s)
+                Q = mfma(tfrag8(ks, 16 * s, 32 * wj, lane), row8(ws, 32 * wi + l31, 16 * s + 8 * hf), Q);
+            Q = prod_accA(Q, T0, T1, gs, 32 * wi + l31, hf);
+            {
+                bf16x8 hi, lo;
+                acc_frag(Ta, 0, hi, lo);
+                const bf16x8 b = first_if(hf == 0, dden_i);
+                Q = mfma(hi, b, Q);
+                Q = mfma(lo, b, Q);
+            }
+            put_acc_T_f32(os, 32 * wi + l31, 32 * wj, Q, hf);
+        }
+        // ST_t[m][e] += sum_j v[j][32t+m] kf[j][32wj+e] ;  Ta[0][e] += sum_j kf[j][32wj+e]
+#pragma unroll 2
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 b = tfrag8(ks, 16 * s, 32 * wj, lane);
+            T0 = mfma(tfrag8(vs, 16 * s, 0, lane), b, T0);
+            T1 = mfma(tfrag8(vs, 16 * s, 32, lane), b, T1);
+            Ta = mfma(ones0, b, Ta);
+        }
+        __syncthreads();
+    }
+    CLA_STORE(nch - 1);
+#undef CLA_LOAD
+#undef CLA_STORE
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward, dK and dV (reverse scan).
+//   dkf_j = sum_{i>=j} W_ij qf_i = (W^T qf)_j + R_next v_j + r1_next ;  dK = dkf * phi'(K),  phi' = min(phi, 1)
+//   dv_j  = sum_{i>=j} A_ij g_i  = (A^T g)_j + R_next^T kf_j
+//   R[e][m] = sum_{i later} qf_i[e] g_i[m],  r1[e] = sum_{i later} qf_i[e] dden_i
+// wave (wi, wj): W and A tiles (i-half wi, j-half wj); dk tile (j-half wi, e-half wj); dv tile (j-half wi, m-half wj).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cla_bwd_dkdv_bf16_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo,
+    long lddk, long lddv) {
+    __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // phi(q)  [i][e]
+    __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
+    __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
+    __shared__ __attribute__((aligned(16))) bf16_t gs[C * LD];   // g       [i][m]
+    __shared__ __attribute__((aligned(16))) bf16_t wt[C * LD];   // masked W^T [j][i]
+    __shared__ __attribute__((aligned(16))) bf16_t at[C * LD];   // masked A^T [j][i]
+    __shared__ __attribute__((aligned(16))) bf16_t ok_[C * LD];  // dkf tile [j][e] (bf16)
+    __shared__ __attribute__((aligned(16))) bf16_t ov[C * LD];   // dv tile  [j][m] (bf16)
+    __shared__ float dd[C];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = w >> 1, wj = w & 1;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int n = blockIdx.x / H, h = blockIdx.x % H;
+    const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
+    const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
+    const bf16_t* vb = v + ((long)n * L) * ldv + h * D;
+    const bf16_t* ob = out + ((long)n * L) * ldo + h * D;
+    const bf16_t* gb = dout + ((long)n * L) * lddo + h * D;
+    const float* zb = zinv + ((long)n * L) * H + h;
+    bf16_t* dkb = dk + ((long)n * L) * lddk + h * D;
+    bf16_t* dvb = dv + ((long)n * L) * lddv + h * D;
+
+    const int srow = tid >> 3, scol = (tid & 7) * 8;
+    const int nch = (L + C - 1) / C;
+    const uint4 u4z = make_uint4(0, 0, 0, 0);
+    uint4 rq[2], rk[2], rv[2], rg[2], ro[2];
+    float rz[2];
+
+#define CLA_LOAD(c)                                                                      \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
+        const long row = (long)(c) * C + srow + 32 * it;                                 \
+        const bool ok = row < L;                                                         \
+        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : u4z;      \
+        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : u4z;      \
+        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : u4z;      \
+        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : u4z;     \
+        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : u4z;      \
+        rz[it] = ok ? zb[row * H] : 0.f;                                                 \
+    }
+    // store slot (row, scol): each thread reads exactly the ks slot it re-stages next, so no barrier is needed
+#define CLA_STORE(c)                                                                     \
+    _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
+        const int row = srow + 32 * it;                                                  \
+        const long grow = (long)(c) * C + row;                                           \
+        if (grow < L) {                                                                  \
+            float x[8], f[8];                                                            \
+            unpack8(*reinterpret_cast<const uint4*>(ok_ + row * LD + scol), x);          \
+            unpack8(*reinterpret_cast<const uint4*>(ks + row * LD + scol), f);           \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] *= fminf(f[j], 1.0f);     \
+            *reinterpret_cast<uint4*>(dkb + grow * lddk + scol) = pack8(x);              \
+            *reinterpret_cast<uint4*>(dvb + grow * lddv + scol) =                        \
+                *reinterpret_cast<const uint4*>(ov + row * LD + scol);                   \
+        }                                                                                \
+    }
+
+    CLA_LOAD(nch - 1);
+    f32x16 RT0 = zero16(), RT1 = zero16();  // RT_t[m][e] = R[32wj+e][32t+m]: rows m on regs, cols e on lanes
+    f32x16 RTa = zero16();                  // RTa[0][e] = r1[32wj + e]
+    f32x16 R20 = zero16(), R21 = zero16();  // R2_t[e][m] = R[32t+e][32wj+m]: rows e on regs, cols m on lanes
+
+    for (int c = nch - 1; c >= 0; --c) {
+        if (c < nch - 1) { CLA_STORE(c + 1); }
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = srow + 32 * it;
+            const bool ok = c * C + row < L;
+            float dden;
+            const uint4 gp = stage_g(rg[it], ro[it], rz[it], dden);
+            if ((tid & 7) == 0) dd[row] = dden;
+            put_row(gs, row, scol, gp);
+            put_row(vs, row, scol, rv[it]);
+            float x[8];
+            unpack8(rk[it], x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+            put_row(ks, row, scol, pack8(x));
+            unpack8(rq[it], x);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+            put_row(qs, row, scol, pack8(x));
+        }
+        __syncthreads();
+        if (c > 0) { CLA_LOAD(c - 1); }
+
+        // W and A tiles (rows i on regs, cols j on lanes), kept where i >= j, written transposed: wt[j][i], at[j][i]
+        if (!(wi == 0 && wj == 1)) {
+            f32x16 W = prod_rows(zero16(), gs, 32 * wi + l31, vs, 32 * wj + l31, 0, 4, hf);
+            // + dden_i * 1 (augmentation k-step: A = [dden_i at k=0], B = [1 at k=0])
+            W = mfma(first_if(hf == 0, dd[32 * wi + l31]), first_if(hf == 0, 1.0f), W);
+            put_acc_T(wt, 32 * wj + l31, 32 * wi, W, hf, wi == wj ? l31 : 0, 64, 0.f);
+            const f32x16 A = prod_rows(zero16(), qs, 32 * wi + l31, ks, 32 * wj + l31, 0, 4, hf);
+            put_acc_T(at, 32 * wj + l31, 32 * wi, A, hf, wi == wj ? l31 : 0, 64, 0.f);
+        }
+        __syncthreads();
+
+        {
+            // contraction over i >= j: for j-half 1 only i-half 1 contributes
+            const int s0 = wi == 1 ? 2 : 0;
+            // dkf^T tile (rows e on regs, cols j on lanes) = qf^T W + RT^T v^T + r1 (x) 1
+            f32x16 K = zero16();
+#pragma unroll 2
+            for (int s = s0; s < 4; ++s)
+                K = mfma(tfrag8(qs, 16 * s, 32 * wj, lane), row8(wt, 32 * wi + l31, 16 * s + 8 * hf), K);
+            K = prod_accA(K, RT0, RT1, vs, 32 * wi + l31, hf);
+            {
+                bf16x8 hi, lo;
+                acc_frag(RTa, 0, hi, lo);
+                const bf16x8 b = first_if(hf == 0, 1.0f);
+                K = mfma(hi, b, K);
+                K = mfma(lo, b, K);
+            }
+            put_acc_T(ok_, 32 * wi + l31, 32 * wj, K, hf, 0, 64, 0.f);
+            // dv^T tile (rows m on regs, cols j on lanes) = g^T A + R2^T kf^T
+            f32x16 V = zero16();
+#pragma unroll 2
+            for (int s = s0; s < 4; ++s)
+                V = mfma(tfrag8(gs, 16 * s, 32 * wj, lane), row8(at, 32 * wi + l31, 16 * s + 8 * hf), V);
+            V = prod_accA(V, R20, R21, ks, 32 * wi + l31, hf);
+            put_acc_T(ov, 32 * wi + l31, 32 * wj, V, hf, 0, 64, 0.f);
+        }
+        // RT_t[m][e] += sum_i g[i][32t+m] qf[i][32wj+e] ; RTa[0][e] += sum_i dden_i qf[i][32wj+e]
+        // R2_t[e][m] += sum_i qf[i][32t+e] g[i][32wj+m]
+#pragma unroll 2
+        for (int s = 0; s < 4; ++s) {
+            const bf16x8 g0 = tfrag8(gs, 16 * s, 0, lane), g1 = tfrag8(gs, 16 * s, 32, lane);
+            const bf16x8 q0 = tfrag8(qs, 16 * s, 0, lane), q1 = tfrag8(qs, 16 * s, 32, lane);
+            const bf16x8 bq = wj == 0 ? q0 : q1;
+            const bf16x8 bg = wj == 0 ? g0 : g1;
+            RT0 = mfma(g0, bq, RT0);
+            RT1 = mfma(g1, bq, RT1);
+            R20 = mfma(q0, bg, R20);
+            R21 = mfma(q1, bg, R21);
+            // A operand row 0 = dden over this k-step's 8 tokens (lane l31 == 0 only), hi + lo
+            bf16x8 dh, dl;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float x = l31 == 0 ? dd[16 * s + 8 * hf + j] : 0.f;
+                const __bf16 hh = (__bf16)x;
+                dh[j] = hh;
+                dl[j] = (__bf16)(x - (float)hh);
+            }
+            RTa = mfma(dh, bq, RTa);
+            RTa = mfma(dl, bq, RTa);
+        }
+        __syncthreads();
+    }
+    CLA_STORE(0);
+#undef CLA_LOAD
+#undef CLA_STORE
+}
+
+}  // namespace b16
+
+int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H, int L,
+                        long ldq, long ldk, long ldv, long ldo, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps);
+    return (int)hipGetLastError();
+}
+
+int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                           const void* dout, void* dq, int N, int H, int L, long ldq, long ldk, long ldv, long ldo,
+                           long lddo, long lddq, hipStream_t st) {
+    hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                       (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dq, H, L, ldq, ldk,
+                       ldv, ldo, lddo, lddq);
+    return (int)hipGetLastError();
+}
+
+int launch_cla_bwd_dkdv_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                             const void* dout, void* dk, void* dv, int N, int H, int L, long ldq, long ldk, long ldv,
+                             long ldo, long lddo, long lddk, long lddv, hipStream_t st) {
+    hipLaunchKernelGGL(b16::cla_bwd_dkdv_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dk,
+                       (bf16_t*)dv, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv);
+    return (int)hipGetLastError();
+}
+
+}  // namespace cwlt

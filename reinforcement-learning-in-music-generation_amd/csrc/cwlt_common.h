@@ -115,4 +115,15 @@ static inline uint32_t drop_thresh(float p) {
 int launch_colsum_finalize(const float* part, float* out, int nblocks, long stride, int ncols, float scale,
                            int accumulate, hipStream_t st);
 
+
+// bf16 throughput path of the causal linear attention (cla_bf16.hip); row strides must be multiples of 8
+int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H, int L,
+                        long ldq, long ldk, long ldv, long ldo, float eps, hipStream_t st);
+int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                           const void* dout, void* dq, int N, int H, int L, long ldq, long ldk, long ldv, long ldo,
+                           long lddo, long lddq, hipStream_t st);
+int launch_cla_bwd_dkdv_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                             const void* dout, void* dk, void* dv, int N, int H, int L, long ldq, long ldk, long ldv,
+                             long ldo, long lddo, long lddk, long lddv, hipStream_t st);
+
 }  // namespace cwlt

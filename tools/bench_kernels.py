@@ -1,0 +1,45 @@
+"""Micro-benchmark of individual libcwlt entry points at the bench shape (GPU box only).
+usage: python tools/bench_kernels.py [B] [T]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import rlmg_amd  # noqa: F401
+from rlmg_amd import ops
+
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(n):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n
+
+
+def main():
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 1024
+    dev = torch.device("cuda:0")
+    H, D = 8, 64
+    for dt in (torch.bfloat16, torch.float32):
+        s = 2 if dt == torch.bfloat16 else 4
+        qkv = torch.randn(B, T, 3, H, D, device=dev).to(dt)
+        dout = torch.randn(B, T, H, D, device=dev).to(dt)
+        q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+        _, _, _, out, zinv = ops.cla_fwd(q, k, v)
+        R = B * T
+        t = timeit(lambda: ops.cla_fwd(q, k, v))
+        print("%-8s cla_fwd   %8.1f us  %7.1f GB/s (algorithmic)" % (dt, t * 1e3, R * 4 * 512 * s / t / 1e6))
+        t = timeit(lambda: ops.cla_bwd(q, k, v, out, zinv, dout))
+        print("%-8s cla_bwd   %8.1f us  %7.1f GB/s (algorithmic, 7 streams)" % (dt, t * 1e3, R * 7 * 512 * s / t / 1e6))
+
+
+if __name__ == "__main__":
+    main()
