@@ -118,10 +118,12 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
+    ap.add_argument("--tune-gemms", action="store_true", help="re-tune the hipBLASLt/rocBLAS table (GPU box)")
+    ap.add_argument("--no-tuned-gemms", action="store_true")
     args = ap.parse_args()
 
     import rlmg_amd  # noqa: F401
-    from rlmg_amd import dist as rdist, ops
+    from rlmg_amd import dist as rdist, gemm_tuning, ops
     from rlmg_amd.dqn_policy import model
 
     rank, local, world = rdist.init_from_env()
@@ -132,6 +134,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
+    if args.tune_gemms:
+        gemm_tuning.tune(os.path.join(ROOT, "gpurun_out", "gemm_gfx950.csv"))
+        tuned = "tuning"
+    else:
+        tuned = (not args.no_tuned_gemms) and gemm_tuning.enable()
+    log("tuned GEMM table: %s" % tuned)
     torch.manual_seed(0)                               # identical replicas on every rank
     n_class = [56, 135, 18, 87, 18, 25]
     import contextlib
@@ -166,6 +174,9 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             log("first step done")
+            if args.tune_gemms:
+                gemm_tuning.save(os.path.join(ROOT, "gpurun_out", "gemm_gfx950.csv"))
+                log("tuned table written")
     fence()
     log("warm-up done, timing %d steps" % args.steps)
     ops.KernelTimer.reset(rank == 0 and not args.no_kernel_timer)
@@ -214,7 +225,8 @@ def main():
             "config": {"workload": "agent_pretrain step (fwd+bwd+clip+Adam), repo dims 512/12/8/2048, "
                                    "synthetic CW tokens (B=%d/GPU, T=%d, 7 fields -> 6)" % (B, T),
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
-                       "parallelism": "dp%d" % world, "dropout": 0.1, "params": 38982227},
+                       "parallelism": "dp%d" % world, "dropout": 0.1, "params": 38982227,
+                       "gemm_table": str(tuned)},
             "final_loss": round(float(loss.item()), 4),
             "model_mfma_frac": round(tokens_per_s / world * FLOP_PER_TOKEN / MFMA_BF16_PEAK, 4),
             "roofline": roofline, "kernels": kernels,

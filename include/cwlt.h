@@ -72,18 +72,19 @@ int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const
  *   x = x + self.dropout(attn(...)); x = self.norm1(x); ... ; self.norm2(x + self.dropout(ffn));
  * and TransformerEncoder's final self.norm(x) (x == NULL, p == 0).
  * x may be NULL (plain LayerNorm of a); s_out may be NULL; mean/rstd (rows) f32 are saved stats.
- * D % 4 == 0, D <= 1024.  Dropout masks are regenerated from (seed, element index) in backward. */
+ * D % 8 == 0, D <= 1024.  Dropout masks are regenerated from (seed, element index) in backward. */
 int cwlt_ln_blocks(int64_t rows);
 int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* gamma, const float* beta,
                                    void* s_out, void* y, float* mean, float* rstd,
                                    int64_t rows, int D, float eps, float p, uint64_t seed,
                                    int dtype, void* stream);
 /* dy2 (optional second upstream gradient, summed with dy), ds = d/ds (also the residual gradient),
- * da = dropout-masked ds (may be NULL or alias ds when p == 0).  part: cwlt_ln_blocks(rows)*3*D f32
- * workspace; dgamma, dbeta (D) f32; dbias (D) f32 = column sum of da (NULL to skip). */
+ * da = dropout-masked ds (NULL when p == 0: then da == ds).  part: cwlt_ln_blocks(rows)*3*D f32
+ * workspace; stats: (3, D) f32 output = dgamma | dbeta | dbias, where dbias = column sum of da,
+ * i.e. the bias gradient of the Linear that produced `a`. */
 int cwlt_add_dropout_layernorm_bwd(const void* dy, const void* dy2, const void* s, const float* gamma,
                                    const float* mean, const float* rstd, void* ds, void* da,
-                                   float* part, float* dgamma, float* dbeta, float* dbias,
+                                   float* part, float* stats,
                                    int64_t rows, int D, float p, uint64_t seed, int dtype, void* stream);
 
 /* ---- deterministic column sums (bias gradients) -------------------------------------------------
@@ -95,7 +96,7 @@ int cwlt_colsum(const void* x, float* part, float* out, int64_t rows, int ncols,
 
 /* ---- FFN activation: g = dropout_p(gelu(h + bias)) ----------------------------------------------
  * Replaces `self.dropout(self.activation(self.linear1(y)))` (activation='gelu' = exact erf,
- * dqn_policy/model.py:134) with the Linear run bias-free.  bias may be NULL.  F % 4 == 0. */
+ * dqn_policy/model.py:134) with the Linear run bias-free.  bias may be NULL.  F % 8 == 0. */
 int cwlt_rowslab_blocks(int64_t rows);
 int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_t rows, int F,
                                float p, uint64_t seed, int dtype, void* stream);

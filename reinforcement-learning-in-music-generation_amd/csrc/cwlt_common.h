@@ -77,6 +77,33 @@ __device__ __forceinline__ void store8(bf16_t* p, const float (&x)[8]) {
     *reinterpret_cast<uint4*>(p) = r;
 }
 
+// 16-byte vector access: VecIO<T>::N elements per lane (4 x f32 or 8 x bf16)
+template <typename T> struct VecIO;
+template <> struct VecIO<float> {
+    static constexpr int N = 4;
+    static __device__ __forceinline__ void load(const float* p, float (&x)[4]) {
+        const float4 a = load4(p);
+        x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w;
+    }
+    static __device__ __forceinline__ void store(float* p, const float (&x)[4]) {
+        store4(p, make_float4(x[0], x[1], x[2], x[3]));
+    }
+};
+template <> struct VecIO<bf16_t> {
+    static constexpr int N = 8;
+    static __device__ __forceinline__ void load(const bf16_t* p, float (&x)[8]) { load8(p, x); }
+    static __device__ __forceinline__ void store(bf16_t* p, const float (&x)[8]) { store8(p, x); }
+};
+// N consecutive f32 parameters (gamma / beta / bias)
+template <int N>
+__device__ __forceinline__ void loadf(const float* p, float (&x)[N]) {
+#pragma unroll
+    for (int i = 0; i < N; i += 4) {
+        const float4 a = load4(p + i);
+        x[i] = a.x; x[i + 1] = a.y; x[i + 2] = a.z; x[i + 3] = a.w;
+    }
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -88,32 +115,55 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
-// Counter-based RNG for dropout: one 32-bit hash per element index, keyed by (seed, stream).
-// The mask is regenerated in backward from the same (seed, index) so no mask tensor is stored.
+// Counter-based RNG for dropout.  One 32-bit hash serves TWO consecutive elements (a 16-bit uniform each),
+// keyed by (seed, element_index >> 1); an element is kept iff its 16 bits >= thresh16 = round(p * 65536).
+// The mask is regenerated in backward from the same (seed, index), so no mask tensor is stored, and it
+// does not depend on the vector width a kernel happens to use.
 __device__ __forceinline__ uint32_t hash32(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
     return x;
 }
-__device__ __forceinline__ uint32_t rng_u32(uint64_t seed, uint64_t idx) {
-    uint32_t lo = (uint32_t)idx, hi = (uint32_t)(idx >> 32);
-    uint32_t s0 = (uint32_t)seed, s1 = (uint32_t)(seed >> 32);
-    return hash32(lo ^ hash32(hi + 0x9e3779b9u + s1) ^ (s0 * 0x85ebca6bu + 0xc2b2ae35u));
+__device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair_idx) {
+    const uint32_t lo = (uint32_t)pair_idx, hi = (uint32_t)(pair_idx >> 32);
+    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9u) ^ (hi * 0x85ebca6bu);
+    return hash32(lo * 0x9e3779b1u ^ key);
 }
-// keep-probability test: keep iff u32 >= thresh, thresh = p * 2^32
-__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
-    return rng_u32(seed, idx) >= thresh;
+// keep flags of N consecutive elements starting at even element offset `off` (N even), bit j = keep
+template <int N>
+__device__ __forceinline__ uint32_t dropout_mask(uint64_t seed, uint64_t off, uint32_t thresh16) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int j = 0; j < N; j += 2) {
+        const uint32_t r = rng_pair(seed, (off >> 1) + (j >> 1));
+        m |= ((r & 0xffffu) >= thresh16 ? 1u : 0u) << j;
+        m |= ((r >> 16) >= thresh16 ? 1u : 0u) << (j + 1);
+    }
+    return m;
+}
+__device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32_t thresh16) {
+    const uint32_t r = rng_pair(seed, idx >> 1);
+    return ((idx & 1) ? (r >> 16) : (r & 0xffffu)) >= thresh16;
 }
 
 // ---- host-side helpers shared by the launchers ------------------------------------------------
+// 16-bit drop threshold and the matching (exact) keep scale 1 / (1 - thresh16 / 65536)
 static inline uint32_t drop_thresh(float p) {
     if (p <= 0.f) return 0u;
-    double t = (double)p * 4294967296.0;
-    if (t > 4294967295.0) t = 4294967295.0;
+    long t = (long)((double)p * 65536.0 + 0.5);
+    if (t < 1) t = 1;
+    if (t > 65535) t = 65535;
     return (uint32_t)t;
+}
+static inline float drop_scale(float p) {
+    const uint32_t t = drop_thresh(p);
+    return t ? (float)(65536.0 / (65536.0 - (double)t)) : 1.0f;
 }
 // out[c] (+)= scale * sum_b part[b*stride + c], fixed summation order (defined in ln.hip)
 int launch_colsum_finalize(const float* part, float* out, int nblocks, long stride, int ncols, float scale,
                            int accumulate, hipStream_t st);
+// nq quantities at once: out + qi*out_stride <- sum_b part[b*stride + qi*ncols + c]
+int launch_colsum_finalize_multi(const float* part, float* out, long out_stride, int nq, int nblocks, long stride,
+                                 int ncols, hipStream_t st);
 
 
 // bf16 throughput path of the causal linear attention (cla_bf16.hip); row strides must be multiples of 8

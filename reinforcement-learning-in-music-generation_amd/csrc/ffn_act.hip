@@ -12,10 +12,35 @@
 
 namespace cwlt {
 
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-erf GELU (F.gelu default).  f32 storage (parity path): libm-accurate erff / expf.
+// bf16 storage: Abramowitz-Stegun 7.1.26 erf (|err| <= 1.5e-7, one v_exp + one v_rcp) -- three orders of
+// magnitude below bf16 resolution and ~3x fewer VALU instructions; the kernel is VALU-bound otherwise.
+template <bool FAST>
+__device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
+    if (FAST) {
+        const float u = fabsf(x) * 0.70710678118654752440f;
+        const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, u, 1.0f));
+        const float e = __expf(-u * u);   // = exp(-x^2 / 2)
+        const float poly =
+            t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+        const float erfa = 1.0f - poly * e;
+        cdf = 0.5f * (1.0f + (x < 0.f ? -erfa : erfa));
+        pdf = 0.39894228040143267794f * e;
+    } else {
+        cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
+        pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    }
+}
+template <bool FAST>
+__device__ __forceinline__ float gelu_f(float x) {
+    float cdf, pdf;
+    gelu_parts<FAST>(x, cdf, pdf);
+    return x * cdf;
+}
+template <bool FAST>
 __device__ __forceinline__ float gelu_grad_f(float x) {
-    const float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752440f));
-    const float pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
+    float cdf, pdf;
+    gelu_parts<FAST>(x, cdf, pdf);
     return cdf + x * pdf;
 }
 
@@ -24,24 +49,28 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* __r
                                                                     const float* __restrict__ bias, T* __restrict__ g,
                                                                     long rows, int F, uint32_t thresh, float keep_scale,
                                                                     uint64_t seed) {
-    const int c4 = blockIdx.x * 256 + threadIdx.x;
-    if (c4 * 4 >= F) return;
-    const float4 b = bias ? load4(bias + c4 * 4) : make_float4(0, 0, 0, 0);
+    constexpr int V = VecIO<T>::N;
+    constexpr bool FAST = sizeof(T) == 2;
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci * V >= F) return;
+    float b[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) b[j] = 0.f;
+    if (bias) loadf<V>(bias + ci * V, b);
     const long per = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
-#pragma unroll 4
+#pragma unroll 2
     for (long r = r0; r < r1; ++r) {
-        const long off = r * F + c4 * 4;
-        const float4 t = load4(h + off);
-        float4 o;
-        o.x = gelu_f(t.x + b.x); o.y = gelu_f(t.y + b.y); o.z = gelu_f(t.z + b.z); o.w = gelu_f(t.w + b.w);
-        if (thresh) {
-            o.x = dropout_keep(seed, off + 0, thresh) ? o.x * keep_scale : 0.f;
-            o.y = dropout_keep(seed, off + 1, thresh) ? o.y * keep_scale : 0.f;
-            o.z = dropout_keep(seed, off + 2, thresh) ? o.z * keep_scale : 0.f;
-            o.w = dropout_keep(seed, off + 3, thresh) ? o.w * keep_scale : 0.f;
+        const long off = r * F + ci * V;
+        float t[V];
+        VecIO<T>::load(h + off, t);
+        const uint32_t km = thresh ? dropout_mask<V>(seed, off, thresh) : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            t[j] = gelu_f<FAST>(t[j] + b[j]);
+            t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
         }
-        store4(g + off, o);
+        VecIO<T>::store(g + off, t);
     }
 }
 
@@ -50,30 +79,34 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_bwd_kernel(const T* __r
                                                                     const float* __restrict__ bias, T* __restrict__ dh,
                                                                     float* __restrict__ part, long rows, int F,
                                                                     uint32_t thresh, float keep_scale, uint64_t seed) {
-    const int c4 = blockIdx.x * 256 + threadIdx.x;
-    if (c4 * 4 >= F) return;
-    const float4 b = bias ? load4(bias + c4 * 4) : make_float4(0, 0, 0, 0);
+    constexpr int V = VecIO<T>::N;
+    constexpr bool FAST = sizeof(T) == 2;
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci * V >= F) return;
+    float b[V], acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) b[j] = acc[j] = 0.f;
+    if (bias) loadf<V>(bias + ci * V, b);
     const long per = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
-    float4 acc = make_float4(0, 0, 0, 0);
-#pragma unroll 4
+#pragma unroll 2
     for (long r = r0; r < r1; ++r) {
-        const long off = r * F + c4 * 4;
-        float4 d = load4(dg + off);
-        const float4 t = load4(h + off);
-        if (thresh) {
-            d.x = dropout_keep(seed, off + 0, thresh) ? d.x * keep_scale : 0.f;
-            d.y = dropout_keep(seed, off + 1, thresh) ? d.y * keep_scale : 0.f;
-            d.z = dropout_keep(seed, off + 2, thresh) ? d.z * keep_scale : 0.f;
-            d.w = dropout_keep(seed, off + 3, thresh) ? d.w * keep_scale : 0.f;
+        const long off = r * F + ci * V;
+        float d[V], t[V];
+        VecIO<T>::load(dg + off, d);
+        VecIO<T>::load(h + off, t);
+        const uint32_t km = thresh ? dropout_mask<V>(seed, off, thresh) : 0xffffffffu;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            d[j] = ((km >> j) & 1u) ? d[j] * keep_scale * gelu_grad_f<FAST>(t[j] + b[j]) : 0.f;
+            acc[j] += d[j];
         }
-        float4 o;
-        o.x = d.x * gelu_grad_f(t.x + b.x); o.y = d.y * gelu_grad_f(t.y + b.y);
-        o.z = d.z * gelu_grad_f(t.z + b.z); o.w = d.w * gelu_grad_f(t.w + b.w);
-        store4(dh + off, o);
-        acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        VecIO<T>::store(dh + off, d);
     }
-    if (part) store4(part + (long)blockIdx.y * F + c4 * 4, acc);
+    if (part) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) part[(long)blockIdx.y * F + ci * V + j] = acc[j];
+    }
 }
 
 // y = dropout(x + pe[t]) with pe (max_len, D) f32, row r of x is position r % T   (model.py:90-92)
@@ -81,28 +114,31 @@ template <typename T>
 __global__ __launch_bounds__(256) void posenc_dropout_kernel(const T* __restrict__ x, const float* __restrict__ pe,
                                                              T* __restrict__ y, long rows, int Tlen, int D,
                                                              uint32_t thresh, float keep_scale, uint64_t seed) {
-    const long n4 = rows * (long)(D >> 2);
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
-        const long r = i / (D >> 2);
-        const int c4 = (int)(i - r * (D >> 2));
-        const long off = r * D + c4 * 4;
-        float4 t = load4(x + off);
+    constexpr int V = VecIO<T>::N;
+    const int nd = D / V;
+    const long nv = rows * (long)nd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const long r = i / nd;
+        const int ci = (int)(i - r * nd);
+        const long off = r * D + ci * V;
+        float t[V];
+        VecIO<T>::load(x + off, t);
         if (pe) {
-            const float4 p = load4(pe + (r % Tlen) * (long)D + c4 * 4);
-            t.x += p.x; t.y += p.y; t.z += p.z; t.w += p.w;
+            float p[V];
+            loadf<V>(pe + (r % Tlen) * (long)D + ci * V, p);
+#pragma unroll
+            for (int j = 0; j < V; ++j) t[j] += p[j];
         }
         if (thresh) {
-            t.x = dropout_keep(seed, off + 0, thresh) ? t.x * keep_scale : 0.f;
-            t.y = dropout_keep(seed, off + 1, thresh) ? t.y * keep_scale : 0.f;
-            t.z = dropout_keep(seed, off + 2, thresh) ? t.z * keep_scale : 0.f;
-            t.w = dropout_keep(seed, off + 3, thresh) ? t.w * keep_scale : 0.f;
+            const uint32_t km = dropout_mask<V>(seed, off, thresh);
+#pragma unroll
+            for (int j = 0; j < V; ++j) t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
         }
-        store4(y + off, t);
+        VecIO<T>::store(y + off, t);
     }
 }
 
 }  // namespace cwlt
-
 extern "C" {
 
 int cwlt_rowslab_blocks(int64_t rows) {
@@ -115,12 +151,13 @@ int cwlt_rowslab_blocks(int64_t rows) {
 int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_t rows, int F, float p, uint64_t seed,
                                int dtype, void* stream) {
     using namespace cwlt;
-    if (!h || !g || rows < 0 || F <= 0 || (F & 3) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (!h || !g || rows < 0 || F <= 0 || (F & 7) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
-    const dim3 grid((F / 4 + 255) / 256, cwlt_rowslab_blocks(rows)), block(256);
+    const int vec = dtype == CWLT_BF16 ? 8 : 4;
+    const dim3 grid((F / vec + 255) / 256, cwlt_rowslab_blocks(rows)), block(256);
     hipStream_t st = (hipStream_t)stream;
     const uint32_t th = drop_thresh(p);
-    const float ks = 1.0f / (1.0f - p);
+    const float ks = drop_scale(p);
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((bias_gelu_dropout_fwd_kernel<float>), grid, block, 0, st, (const float*)h, bias, (float*)g,
                            (long)rows, F, th, ks, seed);
@@ -136,14 +173,15 @@ int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_
 int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias, void* dh, float* part, float* dbias,
                                int64_t rows, int F, float p, uint64_t seed, int dtype, void* stream) {
     using namespace cwlt;
-    if (!dg || !h || !dh || rows < 0 || F <= 0 || (F & 3) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (!dg || !h || !dh || rows < 0 || F <= 0 || (F & 7) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (dbias && !part) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
     const int nb = cwlt_rowslab_blocks(rows);
-    const dim3 grid((F / 4 + 255) / 256, nb), block(256);
+    const int vec = dtype == CWLT_BF16 ? 8 : 4;
+    const dim3 grid((F / vec + 255) / 256, nb), block(256);
     hipStream_t st = (hipStream_t)stream;
     const uint32_t th = drop_thresh(p);
-    const float ks = 1.0f / (1.0f - p);
+    const float ks = drop_scale(p);
     float* pp = dbias ? part : nullptr;
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((bias_gelu_dropout_bwd_kernel<float>), grid, block, 0, st, (const float*)dg, (const float*)h,
@@ -162,14 +200,14 @@ int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias,
 int cwlt_posenc_dropout(const void* x, const float* pe, void* y, int64_t rows, int T, int D, float p, uint64_t seed,
                         int dtype, void* stream) {
     using namespace cwlt;
-    if (!x || !y || rows < 0 || D <= 0 || (D & 3) || T <= 0 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (!x || !y || rows < 0 || D <= 0 || (D & 7) || T <= 0 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
-    const long n4 = rows * (long)(D / 4);
+    const long n4 = rows * (long)(D / (dtype == CWLT_BF16 ? 8 : 4));
     long nb = (n4 + 255) / 256;
     if (nb > 4096) nb = 4096;
     hipStream_t st = (hipStream_t)stream;
     const uint32_t th = drop_thresh(p);
-    const float ks = 1.0f / (1.0f - p);
+    const float ks = drop_scale(p);
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((posenc_dropout_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, pe, (float*)y,
                            (long)rows, T, D, th, ks, seed);

@@ -6,9 +6,9 @@
 // three (dropout, add, layer_norm), and in backward the column sums that make dgamma / dbeta / the
 // preceding Linear's dbias are accumulated in registers while the rows stream through.
 //
-// Mapping: one wave per row; a lane keeps its 4-element chunks (lane + 64*c) of the row in
-// registers, so every load/store is a fully coalesced wave-wide access; row statistics by wave
-// shuffles; f32 arithmetic whatever the storage dtype.  HBM-bound.
+// Mapping: one wave per row; a lane keeps its 16-byte chunks (lane + 64*c) of the row in registers,
+// so every load/store is a fully coalesced 1 KiB wave-wide access; row statistics by wave shuffles;
+// f32 arithmetic whatever the storage dtype.  HBM-bound.
 #include "cwlt_common.h"
 
 namespace cwlt {
@@ -20,62 +20,65 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
                                                                  T* __restrict__ y, float* __restrict__ mean,
                                                                  float* __restrict__ rstd, long rows, int D, float eps,
                                                                  uint32_t thresh, float keep_scale, uint64_t seed) {
+    constexpr int V = VecIO<T>::N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nd4 = D >> 2;
-    float4 gm[NC], bt[NC];
+    const int nchunk = D / V;
+    float gm[NC][V], bt[NC][V];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int c4 = lane + 64 * c;
-        gm[c] = c4 < nd4 ? load4(gamma + c4 * 4) : make_float4(0, 0, 0, 0);
-        bt[c] = c4 < nd4 ? load4(beta + c4 * 4) : make_float4(0, 0, 0, 0);
+        const int ci = lane + 64 * c;
+        if (ci < nchunk) {
+            loadf<V>(gamma + ci * V, gm[c]);
+            loadf<V>(beta + ci * V, bt[c]);
+        }
     }
     const float invD = 1.0f / (float)D;
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
-        float4 v[NC];
+        float v[NC][V];
         float sum = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int c4 = lane + 64 * c;
-            float4 t = make_float4(0, 0, 0, 0);
-            if (c4 < nd4) {
-                const long off = row * D + c4 * 4;
-                t = load4(a + off);
+            const int ci = lane + 64 * c;
+            if (ci < nchunk) {
+                const long off = row * D + ci * V;
+                VecIO<T>::load(a + off, v[c]);
                 if (thresh) {
-                    t.x = dropout_keep(seed, off + 0, thresh) ? t.x * keep_scale : 0.f;
-                    t.y = dropout_keep(seed, off + 1, thresh) ? t.y * keep_scale : 0.f;
-                    t.z = dropout_keep(seed, off + 2, thresh) ? t.z * keep_scale : 0.f;
-                    t.w = dropout_keep(seed, off + 3, thresh) ? t.w * keep_scale : 0.f;
+                    const uint32_t km = dropout_mask<V>(seed, off, thresh);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[c][j] = ((km >> j) & 1u) ? v[c][j] * keep_scale : 0.f;
                 }
                 if (x) {
-                    const float4 r = load4(x + off);
-                    t.x += r.x; t.y += r.y; t.z += r.z; t.w += r.w;
+                    float r[V];
+                    VecIO<T>::load(x + off, r);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) v[c][j] += r[j];
                 }
-                if (s_out) store4(s_out + off, t);
+                if (s_out) VecIO<T>::store(s_out + off, v[c]);
+#pragma unroll
+                for (int j = 0; j < V; ++j) sum += v[c][j];
             }
-            v[c] = t;
-            sum += (t.x + t.y) + (t.z + t.w);
         }
         const float mu = wave_sum(sum) * invD;
         float sq = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int c4 = lane + 64 * c;
-            if (c4 < nd4) {
-                const float dx = v[c].x - mu, dy = v[c].y - mu, dz = v[c].z - mu, dw = v[c].w - mu;
-                sq += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+            if (lane + 64 * c < nchunk) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    const float d = v[c][j] - mu;
+                    sq = fmaf(d, d, sq);
+                }
             }
         }
         const float rs = rsqrtf(wave_sum(sq) * invD + eps);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int c4 = lane + 64 * c;
-            if (c4 < nd4) {
-                float4 o;
-                o.x = (v[c].x - mu) * rs * gm[c].x + bt[c].x;
-                o.y = (v[c].y - mu) * rs * gm[c].y + bt[c].y;
-                o.z = (v[c].z - mu) * rs * gm[c].z + bt[c].z;
-                o.w = (v[c].w - mu) * rs * gm[c].w + bt[c].w;
-                store4(y + row * D + c4 * 4, o);
+            const int ci = lane + 64 * c;
+            if (ci < nchunk) {
+                float o[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) o[j] = (v[c][j] - mu) * rs * gm[c][j] + bt[c][j];
+                VecIO<T>::store(y + row * D + ci * V, o);
             }
         }
         if (lane == 0) {
@@ -95,66 +98,64 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const T* __rest
                                                                  T* __restrict__ da, float* __restrict__ part,
                                                                  long rows, int D, uint32_t thresh, float keep_scale,
                                                                  uint64_t seed) {
-    __shared__ float red[4][NC * 256];
+    constexpr int V = VecIO<T>::N;
+    __shared__ float red[4][NC * 64 * V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nd4 = D >> 2;
-    float4 gm[NC], ag[NC], ab[NC], ac[NC];
+    const int nchunk = D / V;
+    float gm[NC][V], ag[NC][V], ab[NC][V], ac[NC][V];
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-        const int c4 = lane + 64 * c;
-        gm[c] = c4 < nd4 ? load4(gamma + c4 * 4) : make_float4(0, 0, 0, 0);
-        ag[c] = ab[c] = ac[c] = make_float4(0, 0, 0, 0);
+        const int ci = lane + 64 * c;
+#pragma unroll
+        for (int j = 0; j < V; ++j) gm[c][j] = ag[c][j] = ab[c][j] = ac[c][j] = 0.f;
+        if (ci < nchunk) loadf<V>(gamma + ci * V, gm[c]);
     }
     const float invD = 1.0f / (float)D;
     for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float4 g[NC], xh[NC];
+        float g[NC][V], xh[NC][V];
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int c4 = lane + 64 * c;
-            g[c] = xh[c] = make_float4(0, 0, 0, 0);
-            if (c4 < nd4) {
-                const long off = row * D + c4 * 4;
-                float4 t = load4(dy + off);
+            const int ci = lane + 64 * c;
+            if (ci < nchunk) {
+                const long off = row * D + ci * V;
+                VecIO<T>::load(dy + off, g[c]);
                 if (dy2) {
-                    const float4 u = load4(dy2 + off);
-                    t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w;
+                    float u[V];
+                    VecIO<T>::load(dy2 + off, u);
+#pragma unroll
+                    for (int j = 0; j < V; ++j) g[c][j] += u[j];
                 }
-                const float4 sv = load4(s + off);
-                float4 h;
-                h.x = (sv.x - mu) * rs; h.y = (sv.y - mu) * rs; h.z = (sv.z - mu) * rs; h.w = (sv.w - mu) * rs;
-                g[c] = t;
-                xh[c] = h;
-                const float dx = t.x * gm[c].x, dyv = t.y * gm[c].y, dz = t.z * gm[c].z, dw = t.w * gm[c].w;
-                s1 += (dx + dyv) + (dz + dw);
-                s2 += (dx * h.x + dyv * h.y) + (dz * h.z + dw * h.w);
+                VecIO<T>::load(s + off, xh[c]);
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    xh[c][j] = (xh[c][j] - mu) * rs;
+                    const float dx = g[c][j] * gm[c][j];
+                    s1 += dx;
+                    s2 = fmaf(dx, xh[c][j], s2);
+                }
             }
         }
         const float m1 = wave_sum(s1) * invD, m2 = wave_sum(s2) * invD;
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int c4 = lane + 64 * c;
-            if (c4 < nd4) {
-                const long off = row * D + c4 * 4;
-                float4 o;
-                o.x = rs * (g[c].x * gm[c].x - m1 - xh[c].x * m2);
-                o.y = rs * (g[c].y * gm[c].y - m1 - xh[c].y * m2);
-                o.z = rs * (g[c].z * gm[c].z - m1 - xh[c].z * m2);
-                o.w = rs * (g[c].w * gm[c].w - m1 - xh[c].w * m2);
-                if (ds) store4(ds + off, o);
-                float4 m = o;
-                if (thresh) {
-                    m.x = dropout_keep(seed, off + 0, thresh) ? o.x * keep_scale : 0.f;
-                    m.y = dropout_keep(seed, off + 1, thresh) ? o.y * keep_scale : 0.f;
-                    m.z = dropout_keep(seed, off + 2, thresh) ? o.z * keep_scale : 0.f;
-                    m.w = dropout_keep(seed, off + 3, thresh) ? o.w * keep_scale : 0.f;
+            const int ci = lane + 64 * c;
+            if (ci < nchunk) {
+                const long off = row * D + ci * V;
+                float o[V], m[V];
+                const uint32_t km = thresh ? dropout_mask<V>(seed, off, thresh) : 0xffffffffu;
+                const float ksc = thresh ? keep_scale : 1.f;
+#pragma unroll
+                for (int j = 0; j < V; ++j) {
+                    o[j] = rs * (g[c][j] * gm[c][j] - m1 - xh[c][j] * m2);
+                    m[j] = ((km >> j) & 1u) ? o[j] * ksc : 0.f;
+                    ag[c][j] = fmaf(g[c][j], xh[c][j], ag[c][j]);
+                    ab[c][j] += g[c][j];
+                    ac[c][j] += m[j];
                 }
-                if (da) store4(da + off, m);
-                ag[c].x += g[c].x * xh[c].x; ag[c].y += g[c].y * xh[c].y;
-                ag[c].z += g[c].z * xh[c].z; ag[c].w += g[c].w * xh[c].w;
-                ab[c].x += g[c].x; ab[c].y += g[c].y; ab[c].z += g[c].z; ab[c].w += g[c].w;
-                ac[c].x += m.x; ac[c].y += m.y; ac[c].z += m.z; ac[c].w += m.w;
+                if (ds) VecIO<T>::store(ds + off, o);
+                if (da) VecIO<T>::store(da + off, m);
             }
         }
     }
@@ -165,9 +166,9 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const T* __rest
         __syncthreads();
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const float4 t = qn == 0 ? ag[c] : (qn == 1 ? ab[c] : ac[c]);
-            float* r = &red[wave][(lane + 64 * c) * 4];
-            r[0] = t.x; r[1] = t.y; r[2] = t.z; r[3] = t.w;
+            float* r = &red[wave][(lane + 64 * c) * V];
+#pragma unroll
+            for (int j = 0; j < V; ++j) r[j] = qn == 0 ? ag[c][j] : (qn == 1 ? ab[c][j] : ac[c][j]);
         }
         __syncthreads();
         for (int col = threadIdx.x; col < D; col += 256)
@@ -175,33 +176,38 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const T* __rest
     }
 }
 
-// out[c] = scale * sum_b part[b*stride + c]   (deterministic fixed-order tree)
-__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
-                                                              int nblocks, long stride, int ncols, float scale,
-                                                              int accumulate) {
-    __shared__ float red[4][64];
+// out[qi*out_stride + c] (+)= scale * sum_b part[b*stride + qi*ncols + c]; 1024 threads = 16 waves per
+// 64 columns, each wave sums a slice of the partial rows, fixed-order combine (deterministic)
+__global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __restrict__ part, float* __restrict__ out,
+                                                               long out_stride, int nblocks, long stride, int ncols,
+                                                               float scale, int accumulate) {
+    __shared__ float red[16][64];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int col = blockIdx.x * 64 + lane;
+    const float* p = part + (long)blockIdx.y * ncols;
     float acc = 0.f;
     if (col < ncols) {
-        const int per = (nblocks + 3) / 4;
+        const int per = (nblocks + 15) / 16;
         const int b0 = wave * per, b1 = min(nblocks, b0 + per);
         float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int b = b0;
         for (; b + 3 < b1; b += 4) {
-            a0 += part[(long)(b + 0) * stride + col];
-            a1 += part[(long)(b + 1) * stride + col];
-            a2 += part[(long)(b + 2) * stride + col];
-            a3 += part[(long)(b + 3) * stride + col];
+            a0 += p[(long)(b + 0) * stride + col];
+            a1 += p[(long)(b + 1) * stride + col];
+            a2 += p[(long)(b + 2) * stride + col];
+            a3 += p[(long)(b + 3) * stride + col];
         }
-        for (; b < b1; ++b) a0 += part[(long)b * stride + col];
+        for (; b < b1; ++b) a0 += p[(long)b * stride + col];
         acc = (a0 + a1) + (a2 + a3);
     }
     red[wave][lane] = acc;
     __syncthreads();
     if (wave == 0 && col < ncols) {
-        const float v = scale * ((red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]));
-        out[col] = accumulate ? out[col] + v : v;
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) t += red[i][lane];
+        float* o = out + (long)blockIdx.y * out_stride + col;
+        *o = accumulate ? *o + scale * t : scale * t;
     }
 }
 
@@ -209,31 +215,51 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* __res
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const T* __restrict__ x, float* __restrict__ part,
                                                              long rows, int ncols, long ld) {
-    const int c4 = blockIdx.x * 256 + threadIdx.x;
-    if (c4 * 4 >= ncols) return;
+    constexpr int V = VecIO<T>::N;
+    const int ci = blockIdx.x * 256 + threadIdx.x;
+    if (ci * V >= ncols) return;
     const long per = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
-    float4 a0 = make_float4(0, 0, 0, 0), a1 = a0;
+    float a0[V], a1[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) a0[j] = a1[j] = 0.f;
     long r = r0;
     for (; r + 1 < r1; r += 2) {
-        const float4 t0 = load4(x + r * ld + c4 * 4);
-        const float4 t1 = load4(x + (r + 1) * ld + c4 * 4);
-        a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
-        a1.x += t1.x; a1.y += t1.y; a1.z += t1.z; a1.w += t1.w;
+        float t0[V], t1[V];
+        VecIO<T>::load(x + r * ld + ci * V, t0);
+        VecIO<T>::load(x + (r + 1) * ld + ci * V, t1);
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+            a0[j] += t0[j];
+            a1[j] += t1[j];
+        }
     }
     if (r < r1) {
-        const float4 t0 = load4(x + r * ld + c4 * 4);
-        a0.x += t0.x; a0.y += t0.y; a0.z += t0.z; a0.w += t0.w;
+        float t0[V];
+        VecIO<T>::load(x + r * ld + ci * V, t0);
+#pragma unroll
+        for (int j = 0; j < V; ++j) a0[j] += t0[j];
     }
-    store4(part + (long)blockIdx.y * ncols + c4 * 4, make_float4(a0.x + a1.x, a0.y + a1.y, a0.z + a1.z, a0.w + a1.w));
+#pragma unroll
+    for (int j = 0; j < V; ++j) part[(long)blockIdx.y * ncols + ci * V + j] = a0[j] + a1[j];
 }
 
 int launch_colsum_finalize(const float* part, float* out, int nblocks, long stride, int ncols, float scale,
                            int accumulate, hipStream_t st) {
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), dim3(256), 0, st, part, out, nblocks, stride,
-                       ncols, scale, accumulate);
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64, 1), dim3(1024), 0, st, part, out, 0L, nblocks,
+                       stride, ncols, scale, accumulate);
     return (int)hipGetLastError();
 }
+
+int launch_colsum_finalize_multi(const float* part, float* out, long out_stride, int nq, int nblocks, long stride,
+                                 int ncols, hipStream_t st) {
+    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64, nq), dim3(1024), 0, st, part, out, out_stride,
+                       nblocks, stride, ncols, 1.0f, 0);
+    return (int)hipGetLastError();
+}
+
+template <typename T>
+static int ln_nc(int D) { return (D / VecIO<T>::N + 63) / 64; }
 
 }  // namespace cwlt
 
@@ -251,20 +277,21 @@ int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* ga
                                    uint64_t seed, int dtype, void* stream) {
     using namespace cwlt;
     if (!a || !gamma || !beta || !y || !mean || !rstd) return CWLT_ERR_ARG;
-    if (rows < 0 || D <= 0 || (D & 3) || D > 1024 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (rows < 0 || D <= 0 || (D & 7) || D > 1024 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
     const uint32_t th = drop_thresh(p);
-    const float ks = 1.0f / (1.0f - p);
+    const float ks = drop_scale(p);
     const dim3 grid(cwlt_ln_blocks(rows)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define CWLT_LN_FWD(T, NC)                                                                                       \
     hipLaunchKernelGGL((add_dropout_ln_fwd_kernel<T, NC>), grid, block, 0, st, (const T*)x, (const T*)a, gamma, \
                        beta, (T*)s_out, (T*)y, mean, rstd, (long)rows, D, eps, th, ks, seed)
-    const int nc = (D + 255) / 256;
     if (dtype == CWLT_F32) {
+        const int nc = ln_nc<float>(D);
         if (nc == 1) CWLT_LN_FWD(float, 1); else if (nc == 2) CWLT_LN_FWD(float, 2); else CWLT_LN_FWD(float, 4);
     } else if (dtype == CWLT_BF16) {
-        if (nc == 1) CWLT_LN_FWD(bf16_t, 1); else if (nc == 2) CWLT_LN_FWD(bf16_t, 2); else CWLT_LN_FWD(bf16_t, 4);
+        const int nc = ln_nc<bf16_t>(D);
+        if (nc == 1) CWLT_LN_FWD(bf16_t, 1); else CWLT_LN_FWD(bf16_t, 2);
     } else {
         return CWLT_ERR_DTYPE;
     }
@@ -272,41 +299,37 @@ int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* ga
     return (int)hipGetLastError();
 }
 
-/* part: f32 workspace of cwlt_ln_blocks(rows) * 3 * D floats; dgamma/dbeta/dbias: (D) f32 outputs
- * (dbias = column sum of da, i.e. the bias gradient of the Linear that produced `a`; may be NULL). */
+/* part: f32 workspace of cwlt_ln_blocks(rows) * 3 * D floats; stats: (3, D) f32 output =
+ * dgamma | dbeta | dbias (dbias = column sum of da = bias gradient of the Linear that produced `a`). */
 int cwlt_add_dropout_layernorm_bwd(const void* dy, const void* dy2, const void* s, const float* gamma,
                                    const float* mean, const float* rstd, void* ds, void* da, float* part,
-                                   float* dgamma, float* dbeta, float* dbias, int64_t rows, int D, float p,
-                                   uint64_t seed, int dtype, void* stream) {
+                                   float* stats, int64_t rows, int D, float p, uint64_t seed, int dtype,
+                                   void* stream) {
     using namespace cwlt;
-    if (!dy || !s || !gamma || !mean || !rstd || !part || !dgamma || !dbeta) return CWLT_ERR_ARG;
-    if (rows < 0 || D <= 0 || (D & 3) || D > 1024 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
-    if (rows == 0) return CWLT_OK;
+    if (!dy || !s || !gamma || !mean || !rstd || !part || !stats) return CWLT_ERR_ARG;
+    if (rows < 0 || D <= 0 || (D & 7) || D > 1024 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return (int)hipMemsetAsync(stats, 0, sizeof(float) * 3 * D, st);
     const uint32_t th = drop_thresh(p);
-    const float ks = 1.0f / (1.0f - p);
+    const float ks = drop_scale(p);
     const int nb = cwlt_ln_blocks(rows);
     const dim3 grid(nb), block(256);
-    hipStream_t st = (hipStream_t)stream;
 #define CWLT_LN_BWD(T, NC)                                                                                        \
     hipLaunchKernelGGL((add_dropout_ln_bwd_kernel<T, NC>), grid, block, 0, st, (const T*)dy, (const T*)dy2,      \
                        (const T*)s, gamma, mean, rstd, (T*)ds, (T*)da, part, (long)rows, D, th, ks, seed)
-    const int nc = (D + 255) / 256;
     if (dtype == CWLT_F32) {
+        const int nc = ln_nc<float>(D);
         if (nc == 1) CWLT_LN_BWD(float, 1); else if (nc == 2) CWLT_LN_BWD(float, 2); else CWLT_LN_BWD(float, 4);
     } else if (dtype == CWLT_BF16) {
-        if (nc == 1) CWLT_LN_BWD(bf16_t, 1); else if (nc == 2) CWLT_LN_BWD(bf16_t, 2); else CWLT_LN_BWD(bf16_t, 4);
+        const int nc = ln_nc<bf16_t>(D);
+        if (nc == 1) CWLT_LN_BWD(bf16_t, 1); else CWLT_LN_BWD(bf16_t, 2);
     } else {
         return CWLT_ERR_DTYPE;
     }
 #undef CWLT_LN_BWD
     int e = (int)hipGetLastError();
     if (e) return e;
-    const dim3 fg((D + 63) / 64);
-    hipLaunchKernelGGL(colsum_finalize_kernel, fg, block, 0, st, part, dgamma, nb, (long)3 * D, D, 1.0f, 0);
-    hipLaunchKernelGGL(colsum_finalize_kernel, fg, block, 0, st, part + D, dbeta, nb, (long)3 * D, D, 1.0f, 0);
-    if (dbias)
-        hipLaunchKernelGGL(colsum_finalize_kernel, fg, block, 0, st, part + 2 * D, dbias, nb, (long)3 * D, D, 1.0f, 0);
-    return (int)hipGetLastError();
+    return launch_colsum_finalize_multi(part, stats, (long)D, 3, nb, (long)3 * D, D, st);
 }
 
 int cwlt_colsum_blocks(int64_t rows) {
@@ -320,24 +343,22 @@ int cwlt_colsum_blocks(int64_t rows) {
 int cwlt_colsum(const void* x, float* part, float* out, int64_t rows, int ncols, int64_t ld, int dtype,
                 void* stream) {
     using namespace cwlt;
-    if (!x || !part || !out || rows < 0 || ncols <= 0 || (ncols & 3) || (ld & 3) || ld < ncols) return CWLT_ERR_ARG;
+    if (!x || !part || !out || rows < 0 || ncols <= 0 || (ncols & 7) || (ld & 7) || ld < ncols) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return (int)hipMemsetAsync(out, 0, sizeof(float) * ncols, st);
     const int nb = cwlt_colsum_blocks(rows);
-    const dim3 grid((ncols / 4 + 255) / 256, nb), block(256);
+    const dim3 block(256);
     if (dtype == CWLT_F32)
-        hipLaunchKernelGGL((colsum_partial_kernel<float>), grid, block, 0, st, (const float*)x, part, (long)rows, ncols,
-                           (long)ld);
+        hipLaunchKernelGGL((colsum_partial_kernel<float>), dim3((ncols / 4 + 255) / 256, nb), block, 0, st,
+                           (const float*)x, part, (long)rows, ncols, (long)ld);
     else if (dtype == CWLT_BF16)
-        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)x, part, (long)rows,
-                           ncols, (long)ld);
+        hipLaunchKernelGGL((colsum_partial_kernel<bf16_t>), dim3((ncols / 8 + 255) / 256, nb), block, 0, st,
+                           (const bf16_t*)x, part, (long)rows, ncols, (long)ld);
     else
         return CWLT_ERR_DTYPE;
     int e = (int)hipGetLastError();
     if (e) return e;
-    hipLaunchKernelGGL(colsum_finalize_kernel, dim3((ncols + 63) / 64), block, 0, st, part, out, nb, (long)ncols, ncols,
-                       1.0f, 0);
-    return (int)hipGetLastError();
+    return launch_colsum_finalize(part, out, nb, (long)ncols, ncols, 1.0f, 0, st);
 }
 
 }  // extern "C"

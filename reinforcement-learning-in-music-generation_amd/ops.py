@@ -188,8 +188,7 @@ def ln_bwd(dy, dy2, s, gamma, mean, rstd, p=0.0, seed=0, want_dbias=True):
     part = torch.empty(nb * 3 * D, dtype=torch.float32, device=s.device)
     stats = torch.empty((3, D), dtype=torch.float32, device=s.device)
     _call("cwlt_add_dropout_layernorm_bwd", _lib.dev(dy, "dy"), _lib.opt(dy2), _lib.dev(s), _lib.dev(gamma), _lib.dev(mean), _lib.dev(rstd),
-        _lib.dev(ds), _lib.dev(da) if p > 0 else None, _lib.dev(part), _lib.dev(stats[0]), _lib.dev(stats[1]),
-        _lib.dev(stats[2]) if want_dbias else None, rows, D, float(p), int(seed),
+        _lib.dev(ds), _lib.dev(da) if p > 0 else None, _lib.dev(part), _lib.dev(stats), rows, D, float(p), int(seed),
         _lib.dtype_code(s.dtype), _lib.stream_ptr())
     return ds, da, stats[0], stats[1], (stats[2] if want_dbias else None)
 
@@ -248,7 +247,7 @@ def colsum(x):
     """Deterministic column sums of a (rows, ncols) matrix (row-strided ok) -> (ncols) f32."""
     lib = _lib.load()
     rows, ncols = x.shape
-    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0 or ncols % 4 != 0:
+    if x.stride(1) != 1 or x.stride(0) % 8 != 0 or x.data_ptr() % 16 != 0 or ncols % 8 != 0:
         return x.float().sum(0)
     part = torch.empty(lib.cwlt_colsum_blocks(rows) * ncols, dtype=torch.float32, device=x.device)
     out = torch.empty(ncols, dtype=torch.float32, device=x.device)
