@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library builds for gfx950, loads, and exports every symbol include/cwlt.h declares
+(no compute calls -- there is no GPU here)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    import __graft_entry__ as g
+    g.build()
+    import rlmg_amd  # noqa: F401
+    from rlmg_amd import _lib
+    return _lib
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "cwlt.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(cwlt_\w+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported(built):
+    lib = built.load()
+    names = _declared()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libcwlt.so does not export %s" % n
+
+
+def test_binding_covers_header(built):
+    assert sorted(built.exported_names()) == _declared()
+
+
+def test_abi_version(built):
+    assert built.load().cwlt_abi_version() == built.ABI_VERSION
+
+
+def test_argument_validation_without_gpu(built):
+    """Entry points refuse bad arguments before touching the device."""
+    lib = built.load()
+    null = ctypes.c_void_p(0)
+    assert lib.cwlt_causal_linear_fwd(null, null, null, null, null, 1, 8, 16, 64, 512, 512, 512, 512, 1e-6, 0, null) == 1001
+    buf = ctypes.c_void_p(16)   # non-null dummy; rejected on head_dim before any launch
+    assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 0, null) == 1001
+    assert lib.cwlt_add_dropout_layernorm_fwd(null, null, null, null, null, null, null, null, 4, 512, 1e-5, 0.0, 0, 0, null) == 1001
+    assert lib.cwlt_ln_blocks(65536) == 1024 and lib.cwlt_ln_blocks(1) == 1
+
+
+def test_product_has_no_cpu_fallback(built):
+    """CPU tensors are refused loudly instead of being routed to a fallback."""
+    import torch
+    from rlmg_amd import ops
+    q = torch.zeros(1, 4, 1, 64)
+    with pytest.raises(RuntimeError, match="GPU"):
+        ops.causal_linear_attention(q, q, q)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "reinforcement-learning-in-music-generation_amd")
+    for dp, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)

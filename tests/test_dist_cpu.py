@@ -1,0 +1,81 @@
+"""CPU, world_size 2 over gloo: the data-parallel gradient buckets (rlmg_amd.dist.GradSync) give every
+rank the mean gradient, equal to the single-process gradient of the concatenated batch."""
+import os
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model():
+    torch.manual_seed(0)
+    return torch.nn.Sequential(torch.nn.Linear(16, 32), torch.nn.Tanh(), torch.nn.Linear(32, 8),
+                               torch.nn.Linear(8, 1, bias=False))
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import rlmg_amd  # noqa: F401
+    from rlmg_amd import dist as rdist
+    r, _, w = rdist.init_from_env()
+    assert (r, w) == (rank, world)
+    net = _model()
+    unused = torch.nn.Linear(4, 4)                      # never receives a gradient (like project_concat_type)
+    params = list(net.parameters()) + list(unused.parameters())
+    sync = rdist.GradSync(params, bucket_bytes=256)     # several small buckets
+    assert len(sync.buckets) >= 2
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(8, 16, generator=g)
+    for step in range(2):                                # second step checks zero_grad / re-arming
+        sync.zero_grad()
+        xs = x[rank * 4:(rank + 1) * 4]
+        net(xs).pow(2).mean().backward()
+        sync.finish()
+    total = sync.clip_grad_norm_(1e9)
+    res = {"grads": [p.grad.clone() for p in net.parameters()], "norm": total.item(),
+           "unused": [p.grad.clone() for p in unused.parameters()]}
+    torch.save(res, out % rank)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_gradsync_world2_matches_single_process(tmp_path):
+    port = 29500 + (os.getpid() % 2000)
+    out = str(tmp_path / "r%d.pt")
+    mp.spawn(_worker, args=(2, port, out), nprocs=2, join=True)
+    r0, r1 = torch.load(out % 0), torch.load(out % 1)
+    net = _model()
+    g = torch.Generator().manual_seed(100)
+    x = torch.randn(8, 16, generator=g)
+    # mean over ranks of per-rank means == mean over the whole batch (equal shard sizes)
+    net(x).pow(2).mean().backward()
+    ref = [p.grad for p in net.parameters()]
+    for a, b, c in zip(r0["grads"], r1["grads"], ref):
+        assert torch.allclose(a, b, atol=0, rtol=0)
+        assert torch.allclose(a, c, atol=1e-6)
+    assert all(t.abs().sum().item() == 0 for t in r0["unused"])
+    ref_norm = torch.linalg.vector_norm(torch.cat([t.flatten() for t in ref])).item()
+    assert abs(r0["norm"] - ref_norm) < 1e-5 and abs(r1["norm"] - ref_norm) < 1e-5
+
+
+def test_gradsync_single_process_clip():
+    sys.path.insert(0, ROOT)
+    import rlmg_amd  # noqa: F401
+    from rlmg_amd import dist as rdist
+    net = _model()
+    sync = rdist.GradSync(net.parameters())
+    sync.zero_grad()
+    net(torch.ones(3, 16)).sum().backward()
+    sync.finish()
+    n0 = sync.grad_norm().item()
+    sync.clip_grad_norm_(n0 / 2)
+    assert abs(sync.grad_norm().item() - n0 / 2) < 1e-4 * n0
+    ref = torch.nn.utils.clip_grad_norm_(net.parameters(), 1e9).item()
+    assert abs(ref - n0 / 2) < 1e-4 * n0
