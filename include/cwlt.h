@@ -146,6 +146,17 @@ int cwlt_heads_ce_bwd(const void* logits, const int* n_class, int n_attr, const 
                       const float* mask, const float* coef, void* dlogits, int64_t rows, int64_t ld,
                       int dtype, void* stream);
 
+/* ---- sliding-window attention of the AIRL discriminator (forward) --------------------------------
+ * Replaces HF LongformerSelfAttention.forward (banded scores -> fp32 softmax -> probs @ value) as
+ * reached from dqn_policy/AIRL_model.py:78-90,117 (attention_window 50) and ppo_policy/model.py:440-451,470
+ * (attention_window 512).  q, k, v, out: (B, L, H, 64), row strides ld*; mask (B, L) f32, nonzero =
+ * attend (NULL = all); window = one-sided width (attention_window / 2); scale = 1/sqrt(64) applied to q;
+ * masked queries produce zero rows; p = dropout on the probabilities. */
+int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out,
+                       int B, int H, int L, int head_dim, int window,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                       float scale, float p, uint64_t seed, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,49 @@
+"""Drop-in for /root/reference/dqn_policy/AIRL_model.py: `LongFormer`, the AIRL discriminator
+(10-layer Longformer, window 50, mean-pool + score classifier), forward on the libcwlt kernels."""
+import os
+import sys
+
+import torch
+import torch.nn as nn
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import ops  # noqa: E402
+from rlmg_amd.cw_transformer import ATTRS, Embeddings  # noqa: E402,F401
+from rlmg_amd.discriminator import CWLongformerBase  # noqa: E402
+
+# --- modules config (AIRL_model.py:22-27) --- #
+MAX_SEQ_LEN = 1024
+D_MODEL = 512
+N_LAYER = 10
+N_HEAD = 8
+path_exp = "exp"
+N_STATES = 50
+
+
+class LongFormer(CWLongformerBase):
+    def __init__(self, n_token):
+        super().__init__(n_token, D_MODEL, N_LAYER, N_HEAD, MAX_SEQ_LEN * 2, attention_window=N_STATES)
+        print("Disc token >>>>> ", self.n_token)
+        self._build_longformer()
+        self.score_classifier = nn.Sequential(
+            nn.Linear(D_MODEL, 128), nn.BatchNorm1d(128), nn.Tanh(),
+            nn.Linear(128, 64), nn.Tanh(), nn.Linear(64, 1), nn.Sigmoid())
+
+    def forward(self, data, masks):
+        """data (B, window, 6), masks (B, window) -> (B, 1) in (0, 1)   (AIRL_model.py:101-122)."""
+        with torch.no_grad():
+            seq = self._encode(data, masks)
+            return self.score_classifier(seq.float().mean(dim=1))
+
+    def token_forward(self, data, target, loss_mask):
+        """Mean of the 6 token CE losses of the discriminator's heads (AIRL_model.py:131-170), forward only."""
+        with torch.no_grad():
+            h = self._encode(data, loss_mask)
+            logits = self._fused_logits(h)
+            rows = logits.shape[0]
+            ones = torch.ones(rows, device=logits.device)
+            res = ops.heads_forward(logits, self.n_token, target.reshape(rows, len(self.n_token)), ones)
+            return (res["loss_sum"] / rows).sum() / len(self.n_token)

@@ -1,0 +1,145 @@
+"""Longformer encoder body of the AIRL discriminator / PPO reward model, forward on the libcwlt kernels.
+
+Stands where the reference instantiates HF `LongformerModel(LongformerConfig(...))`
+(dqn_policy/AIRL_model.py:78-90, ppo_policy/model.py:440-451) and calls it as
+`self.longformer(inputs_embeds=x, attention_mask=mask).last_hidden_state`.  Submodule names reproduce the
+HF state-dict keys (`embeddings.{word_embeddings,token_type_embeddings,position_embeddings,LayerNorm}`,
+`encoder.layer.{i}.attention.self.{query,key,value,query_global,key_global,value_global}`,
+`attention.output.{dense,LayerNorm}`, `intermediate.dense`, `output.{dense,LayerNorm}`, `pooler.dense`), so
+reference checkpoints load unchanged; `word_embeddings`, the `*_global` projections and `pooler` exist only
+for that (the reference never uses them: inputs_embeds, no global attention, last_hidden_state).
+
+Semantics restated from transformers' modeling_longformer.py (LongformerEmbeddings / SelfAttention /
+SelfOutput / Intermediate / Output): position ids start at pad_token_id + 1 = 2, token type 0, LayerNorm eps
+1e-12, post-LN residual blocks, exact-erf gelu, band attention with one-sided window = attention_window/2,
+masked keys excluded, masked query rows zeroed.  `position_embedding_type="relative_key"` is ignored by
+Longformer.  Forward only: scoring is what the RL loops use (`update_disc(train=False)`,
+frozen reward model); discriminator training is listed as the next widening step.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+class _Embeddings(nn.Module):
+    def __init__(self, vocab, hidden, max_pos, type_vocab, eps, pad_id):
+        super().__init__()
+        self.word_embeddings = nn.Embedding(vocab, hidden, padding_idx=pad_id)
+        self.token_type_embeddings = nn.Embedding(type_vocab, hidden)
+        self.LayerNorm = nn.LayerNorm(hidden, eps=eps)
+        self.position_embeddings = nn.Embedding(max_pos, hidden, padding_idx=pad_id)
+        self.padding_idx = pad_id
+
+
+class _SelfAttention(nn.Module):
+    def __init__(self, hidden):
+        super().__init__()
+        for name in ("query", "key", "value", "query_global", "key_global", "value_global"):
+            setattr(self, name, nn.Linear(hidden, hidden))
+
+
+class _DenseNorm(nn.Module):
+    def __init__(self, din, dout, eps):
+        super().__init__()
+        self.dense = nn.Linear(din, dout)
+        self.LayerNorm = nn.LayerNorm(dout, eps=eps)
+
+
+class _Dense(nn.Module):
+    def __init__(self, din, dout):
+        super().__init__()
+        self.dense = nn.Linear(din, dout)
+
+
+class _Attention(nn.Module):
+    def __init__(self, hidden, eps):
+        super().__init__()
+        self.self = _SelfAttention(hidden)
+        self.output = _DenseNorm(hidden, hidden, eps)
+
+
+class _Layer(nn.Module):
+    def __init__(self, hidden, inter, eps):
+        super().__init__()
+        self.attention = _Attention(hidden, eps)
+        self.intermediate = _Dense(hidden, inter)
+        self.output = _DenseNorm(inter, hidden, eps)
+
+
+class _Encoder(nn.Module):
+    def __init__(self, n_layer, hidden, inter, eps):
+        super().__init__()
+        self.layer = nn.ModuleList([_Layer(hidden, inter, eps) for _ in range(n_layer)])
+
+
+class LongformerOutput:
+    def __init__(self, last_hidden_state):
+        self.last_hidden_state = last_hidden_state
+
+
+class LongformerModel(nn.Module):
+    """Constructor mirrors the LongformerConfig kwargs the reference passes."""
+
+    def __init__(self, max_position_embeddings, hidden_size, num_hidden_layers, num_attention_heads,
+                 intermediate_size, attention_window, hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1,
+                 vocab_size=30522, type_vocab_size=2, layer_norm_eps=1e-12, pad_token_id=1):
+        super().__init__()
+        if hidden_size // num_attention_heads != 64:
+            raise ValueError("band attention kernel is specialised for 64-wide heads")
+        self.embeddings = _Embeddings(vocab_size, hidden_size, max_position_embeddings, type_vocab_size,
+                                      layer_norm_eps, pad_token_id)
+        self.encoder = _Encoder(num_hidden_layers, hidden_size, intermediate_size, layer_norm_eps)
+        self.pooler = _Dense(hidden_size, hidden_size)
+        self.n_heads = num_attention_heads
+        self.one_sided_window = attention_window // 2
+        self.p_hidden = hidden_dropout_prob
+        self.p_attn = attention_probs_dropout_prob
+        self.eps = layer_norm_eps
+        self.max_pos = max_position_embeddings
+        self.compute_dtype = torch.float32
+
+    @torch.no_grad()
+    def forward(self, inputs_embeds=None, attention_mask=None):
+        if inputs_embeds is None:
+            raise ValueError("the reference always passes inputs_embeds")
+        x = inputs_embeds
+        if not x.is_cuda:
+            raise RuntimeError("rlmg_amd Longformer runs on the GPU only (no CPU fallback)")
+        B, L, Dm = x.shape
+        if L + 2 > self.max_pos:
+            raise RuntimeError("sequence length %d exceeds max_position_embeddings" % L)
+        adt = self.compute_dtype
+        train = self.training
+        ph = self.p_hidden if train else 0.0
+        pa = self.p_attn if train else 0.0
+        emb = self.embeddings
+        # inputs_embeds + position (ids 2..L+1) + token type 0, then LN(eps) and dropout
+        add = emb.position_embeddings.weight[emb.padding_idx + 1: emb.padding_idx + 1 + L] \
+            + emb.token_type_embeddings.weight[0]
+        h = (x.float() + add).to(adt).reshape(B * L, Dm)
+        lnw, lnb = ops._f32(emb.LayerNorm.weight), ops._f32(emb.LayerNorm.bias)
+        _, h, _, _ = ops.ln_fwd(None, h, lnw, lnb, self.eps, 0.0, 0, save_s=False)
+        if ph > 0:
+            h = ops.posenc_dropout(h, None, L, ph, ops.next_seed())
+        mask = None if attention_mask is None else attention_mask.reshape(B, L).float()
+        H = self.n_heads
+        for layer in self.encoder.layer:
+            sa = layer.attention.self
+            wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0).to(adt)
+            bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0).to(adt)
+            qkv = torch.addmm(bqkv, h, wqkv.t()).view(B, L, 3, H, Dm // H)
+            a = ops.band_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask, self.one_sided_window, pa,
+                                   ops.next_seed() if pa > 0 else 0).view(B * L, Dm)
+            ao = layer.attention.output
+            o = torch.addmm(ao.dense.bias.to(adt), a, ao.dense.weight.to(adt).t())
+            _, h1, _, _ = ops.ln_fwd(h, o, ops._f32(ao.LayerNorm.weight), ops._f32(ao.LayerNorm.bias), self.eps, ph,
+                                     ops.next_seed() if ph > 0 else 0, save_s=False)
+            it = layer.intermediate.dense
+            g = ops.gelu_fwd(torch.mm(h1, it.weight.to(adt).t()), ops._f32(it.bias), 0.0, 0)
+            lo = layer.output
+            y = torch.addmm(lo.dense.bias.to(adt), g, lo.dense.weight.to(adt).t())
+            _, h, _, _ = ops.ln_fwd(h1, y, ops._f32(lo.LayerNorm.weight), ops._f32(lo.LayerNorm.bias), self.eps, ph,
+                                    ops.next_seed() if ph > 0 else 0, save_s=False)
+        return LongformerOutput(h.view(B, L, Dm))

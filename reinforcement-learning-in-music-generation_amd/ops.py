@@ -401,5 +401,24 @@ def heads_ce(logits, target, mask, n_class):
     return HeadsCEFn.apply(logits, target, mask, tuple(int(n) for n in n_class))
 
 
+# --------------------------------------------------------------------------------------------------
+# banded attention (AIRL discriminator), forward only
+# --------------------------------------------------------------------------------------------------
+def band_attention(q, k, v, mask, window, p=0.0, seed=0):
+    """q, k, v: (B, L, H, 64) views; mask (B, L) nonzero = attend or None; window = one-sided width.
+    -> (B, L, H*64).  Forward only (discriminator scoring; its training is the next widening step)."""
+    B, L, H, D = q.shape
+    q, ldq = _as_rows(q)
+    k, ldk = _as_rows(k)
+    v, ldv = _as_rows(v)
+    out = torch.empty((B, L, H * D), dtype=q.dtype, device=q.device)
+    if mask is not None:
+        mask = mask.reshape(B, L).float().contiguous()
+    _call("cwlt_band_attn_fwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.opt(mask), _lib.dev(out),
+          B, H, L, D, int(window), ldq, ldk, ldv, H * D, 1.0 / math.sqrt(D), float(p), int(seed),
+          _lib.dtype_code(q.dtype), _lib.stream_ptr())
+    return out
+
+
 def sqrt_width(w):
     return math.sqrt(w)

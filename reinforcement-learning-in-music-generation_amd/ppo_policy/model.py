@@ -15,6 +15,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 import rlmg_amd  # noqa: E402,F401
 from rlmg_amd.cw_transformer import ATTRS, CWTrunk, Embeddings, PositionalEncoding  # noqa: E402,F401
+from rlmg_amd.discriminator import CWLongformerBase  # noqa: E402
 from rlmg_amd.sampling import nucleus, sampling, softmax_with_temperature, weighted_sampling  # noqa: E402,F401
 
 try:
@@ -76,3 +77,31 @@ class Critic_Transformer(CWTrunk):
             total = total + torch.nn.functional.linear(logits[:, o:o + n], head.weight, head.bias)
             o += n
         return total / len(self.n_token)
+
+
+class LongFormer(CWLongformerBase):
+    """ppo_policy/model.py:400-495: the frozen reward model.  12-layer Longformer with attention_window =
+    D_MODEL (512); the reference pads the 50-token window to 512 -- here the band simply covers the window."""
+
+    def __init__(self, n_token):
+        super().__init__(n_token, DiscriConfig["D_MODEL"], DiscriConfig["N_LAYER"], DiscriConfig["N_HEAD"],
+                         DiscriConfig["MAX_SEQ"], attention_window=DiscriConfig["D_MODEL"])
+        for name, n in zip(ATTRS, self.n_token):
+            setattr(self, "eval_" + name, nn.Linear(n, 1))
+        self.sigmoid = nn.Sigmoid()
+        self._build_longformer()
+        self.longformer_config = dict(self._lf_args, position_embedding_type="relative_key", hidden_act="gelu")
+
+    def token_forward(self, data, target, loss_mask):
+        """(B, T, 6), _, (B, T) -> (B, 1): mean over the 6 attributes of sigmoid(mean_T eval_f(proj_f(h))).
+        `target` is unused, as in the reference (:459)."""
+        with torch.no_grad():
+            h = self._encode(data, loss_mask)
+            B, T = h.shape[0], h.shape[1]
+            logits = self._fused_logits(h).float().view(B, T, -1).mean(dim=1)
+            total, o = 0, 0
+            for name, n in zip(ATTRS, self.n_token):
+                head = getattr(self, "eval_" + name)
+                total = total + torch.sigmoid(torch.nn.functional.linear(logits[:, o:o + n], head.weight, head.bias))
+                o += n
+            return total / len(self.n_token)

@@ -134,11 +134,63 @@ def ppo_small():
     config.ActorConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
 
 
+def ppo_reward_small():
+    """ppo_policy/model.py::LongFormer (frozen reward model), eval mode, small dims."""
+    config, model = _import_reference("ppo_policy")
+    config.DiscriConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    n_token = [49, 19, 19, 89, 67, 25]
+    net = fill_params(model.LongFormer(n_token), seed=31).eval()
+    gen = torch.Generator().manual_seed(77)
+    x = _tokens(gen, (3, 50), n_token)
+    mask = torch.ones(3, 50, dtype=torch.long)
+    mask[1, 40:] = 0
+    with torch.no_grad():
+        r = net.token_forward(x, None, mask)
+    np.savez_compressed(os.path.join(HERE, "ppo_reward_small.npz"), x=x.numpy(), mask=mask.numpy(), reward=r.numpy(),
+                        n_token=np.array(n_token), keys=np.array(sorted(net.state_dict().keys())))
+    config.DiscriConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
+
+
+def airl_small():
+    """dqn_policy/AIRL_model.py::LongFormer (AIRL discriminator), eval mode.  Its module-level constants are
+    patched to a small net after import; line 10's dead import of TrajectoryTransformer* (gone from the
+    transformers release in this image) is satisfied with placeholder names that nothing uses."""
+    import transformers
+    for name in ("TrajectoryTransformerConfig", "TrajectoryTransformerModel"):
+        if not hasattr(transformers, name):
+            setattr(transformers, name, type(name, (), {}))
+    from oracle import ft_standin
+    ft_standin.install()
+    sys.modules.pop("AIRL_model", None)
+    path = os.path.join(REF, "dqn_policy")
+    sys.path.insert(0, path)
+    try:
+        am = importlib.import_module("AIRL_model")
+    finally:
+        sys.path.remove(path)
+    am.D_MODEL, am.N_LAYER, am.N_HEAD = 128, 2, 2
+    n_class = [56, 135, 18, 87, 18, 25]
+    net = fill_params(am.LongFormer(n_class), seed=41).eval()
+    with torch.no_grad():      # non-trivial BatchNorm running statistics
+        net.score_classifier[1].running_mean.copy_(torch.linspace(-0.2, 0.2, 128))
+        net.score_classifier[1].running_var.copy_(torch.linspace(0.5, 1.5, 128))
+    gen = torch.Generator().manual_seed(78)
+    x = _tokens(gen, (4, 50), n_class)
+    mask = torch.ones(4, 50, dtype=torch.long)
+    mask[2, 45:] = 0
+    with torch.no_grad():
+        score = net(x, mask)
+    np.savez_compressed(os.path.join(HERE, "airl_small.npz"), x=x.numpy(), mask=mask.numpy(), score=score.numpy(),
+                        n_class=np.array(n_class), keys=np.array(sorted(net.state_dict().keys())))
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     dqn_small()
     dqn_repo_dims()
     ppo_small()
+    ppo_reward_small()
+    airl_small()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

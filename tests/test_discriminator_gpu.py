@@ -1,0 +1,99 @@
+"""GPU: banded attention kernel and the Longformer discriminators vs the reference fixtures / the oracle."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from fill import fill_params  # noqa: E402
+
+import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import ops  # noqa: E402
+from oracle import discriminator as odisc, longformer as olf  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _load(name):
+    return np.load(os.path.join(HERE, "golden", name), allow_pickle=False)
+
+
+@pytest.mark.parametrize("B,L,H,w", [(2, 50, 8, 25), (1, 50, 2, 256), (3, 70, 1, 8), (2, 200, 2, 25), (1, 1, 1, 3)])
+def test_band_attention_matches_oracle(cuda, B, L, H, w):
+    g = torch.Generator().manual_seed(L + w)
+    q, k, v = (torch.randn(B, L, H, 64, generator=g) for _ in range(3))
+    mask = torch.ones(B, L)
+    if L > 10:
+        mask[0, L - 5:] = 0
+        mask[-1, 2] = 0
+    ref = olf.band_attention(q.double(), k.double(), v.double(), mask, w)
+    got = ops.band_attention(q.to(cuda), k.to(cuda), v.to(cuda), mask.to(cuda), w)
+    assert (got.cpu().double() - ref).abs().max().item() < TOL
+    got2 = ops.band_attention(q.to(cuda), k.to(cuda), v.to(cuda), None, w)
+    ref2 = olf.band_attention(q.double(), k.double(), v.double(), None, w)
+    assert (got2.cpu().double() - ref2).abs().max().item() < TOL
+
+
+def test_band_attention_dropout_is_unbiased(cuda):
+    B, L, H, w = 4, 50, 8, 25
+    q, k, v = (torch.randn(B, L, H, 64, device=cuda) for _ in range(3))
+    base = ops.band_attention(q, k, v, None, w)
+    acc = torch.zeros_like(base)
+    n = 64
+    for s in range(n):
+        acc += ops.band_attention(q, k, v, None, w, p=0.1, seed=1000 + s)
+    assert (acc / n - base).abs().mean().item() < 0.05 * base.abs().mean().item() + 0.02
+
+
+def test_airl_discriminator_matches_reference_fixture(cuda):
+    from rlmg_amd.dqn_policy import AIRL_model
+    fx = _load("airl_small.npz")
+    old = (AIRL_model.D_MODEL, AIRL_model.N_LAYER, AIRL_model.N_HEAD)
+    AIRL_model.D_MODEL, AIRL_model.N_LAYER, AIRL_model.N_HEAD = 128, 2, 2
+    try:
+        net = fill_params(AIRL_model.LongFormer(fx["n_class"].tolist()), seed=41)
+    finally:
+        AIRL_model.D_MODEL, AIRL_model.N_LAYER, AIRL_model.N_HEAD = old
+    assert sorted(net.state_dict().keys()) == fx["keys"].tolist()
+    with torch.no_grad():
+        net.score_classifier[1].running_mean.copy_(torch.linspace(-0.2, 0.2, 128))
+        net.score_classifier[1].running_var.copy_(torch.linspace(0.5, 1.5, 128))
+    net = net.to(cuda).eval()
+    x, mask = torch.from_numpy(fx["x"]).to(cuda), torch.from_numpy(fx["mask"]).to(cuda)
+    score = net(x, mask)
+    assert (score.cpu() - torch.from_numpy(fx["score"])).abs().max().item() < TOL
+
+
+def test_ppo_reward_model_matches_reference_fixture(cuda):
+    from rlmg_amd.ppo_policy import config as pcfg, model as pmodel
+    fx = _load("ppo_reward_small.npz")
+    old = dict(pcfg.DiscriConfig)
+    pcfg.DiscriConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    try:
+        net = fill_params(pmodel.LongFormer(fx["n_token"].tolist()), seed=31)
+    finally:
+        pcfg.DiscriConfig.update(old)
+    assert sorted(net.state_dict().keys()) == fx["keys"].tolist()
+    net = net.to(cuda).eval()
+    x, mask = torch.from_numpy(fx["x"]).to(cuda), torch.from_numpy(fx["mask"]).to(cuda)
+    r = net.token_forward(x, None, mask)
+    assert (r.cpu() - torch.from_numpy(fx["reward"])).abs().max().item() < TOL
+
+
+def test_airl_repo_dims_matches_oracle(cuda):
+    """Full-size discriminator (512 / 10 layers / 8 heads, window 50) on 100 windows vs the CPU oracle."""
+    from rlmg_amd.dqn_policy import AIRL_model
+    n_class = [56, 135, 18, 87, 18, 25]
+    net = fill_params(AIRL_model.LongFormer(n_class), seed=5).eval()
+    g = torch.Generator().manual_seed(4)
+    x = torch.stack([torch.randint(0, n, (100, 50), generator=g) for n in n_class], -1)
+    mask = torch.ones(100, 50, dtype=torch.long)
+    mask[7, 30:] = 0
+    sd = {k: v.detach() for k, v in net.state_dict().items()}
+    want = odisc.airl_forward(sd, x, mask, 10, 8, 50)
+    got = net.to(cuda)(x.to(cuda), mask.to(cuda))
+    assert (got.cpu() - want).abs().max().item() < TOL
