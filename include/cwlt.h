@@ -157,6 +157,40 @@ int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float*
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                        float scale, float p, uint64_t seed, int dtype, void* stream);
 
+/* Gradient of sum_{r,f} w[r][f] * log softmax_f(logits_r)[target[r][f]] w.r.t. the logits, given as the kernel
+ * form dlogits = (softmax - onehot(target)) * w: pass w = -(upstream gradient).  Used for the PPO log pi(a)
+ * of the greedy action (ppo_policy/ppo_train.py:320-336).  w (rows, n_attr) f32 on device. */
+int cwlt_heads_logp_bwd(const void* logits, const int* n_class, int n_attr, const int64_t* target,
+                        const float* w, void* dlogits, int64_t rows, int64_t ld, int dtype, void* stream);
+
+/* ---- RL arithmetic (one launch each; the reference's indexing quirks reproduced) -----------------
+ * cwlt_rollout_gather: greedy action rows (+ log-probs) from per-position argmax ids (R, T, A) int64 and
+ *   softmax probs (R, T, ldp) f32.  mode 0 = DQN.choose_action (dqn_policy/IRL_dqn_train.py:256-264:
+ *   positions [0, T-1, T-2, ...] because -0 == 0); mode 1 = PPO.choose_action (ppo_policy/ppo_train.py:
+ *   269-290: rows at -1..-NA, tempo/chord log-prob class taken at position +idx); mode 2 = select_udpate
+ *   (ppo_train.py:312-336, no quirk).  action (R, NA, A) int64, logp (R, NA, A) f32 (modes 1, 2). */
+int cwlt_rollout_gather(const int64_t* ids, const float* probs, const int* n_class, int n_attr,
+                        int64_t* action, float* logp, int R, int T, int NA, int64_t ldp, int mode,
+                        void* stream);
+/* PPO.calculate_returns + calculate_advantages (ppo_train.py:348-363): forward-order discounted sums,
+ * (x - mean) / unbiased std, adv = returns - values, normalised.  E in [2, 8192]. */
+int cwlt_ppo_returns_adv(const float* rewards, const float* values, float* returns, float* adv, int E,
+                         float gamma, int normalize, void* stream);
+/* PPO surrogate (ppo_train.py:388-396): L = -mean(min(0.2*A_e, clamp(exp(new - old), 1-clip, 1+clip)*A_e));
+ * new_logp (NA, A) f32, old_logp (E, NA, A) int64 (stored log-probs truncated to integers), adv (E) f32.
+ * Outputs loss (1) and grad (NA, A) = dL/dnew_logp. */
+int cwlt_ppo_policy_loss(const float* new_logp, const int64_t* old_logp, const float* adv, float* loss,
+                         float* grad, int E, int NA, int n_attr, float clip, void* stream);
+/* DQN TD loss (dqn_policy/IRL_dqn_train.py:285-330): q gather from batch element 0 (index shape (1, B, NA)),
+ * target = reward + gamma (1 - done) topk_NA(max_c target_logits), per-attribute MSE.  y, yt (B, T, ld) f32.
+ * mse_part (B, A): sum_k squared error; dq (B, NA, A): d MSEloss / d qval. */
+int cwlt_dqn_td_fwd(const float* y, const float* yt, const int* n_class, int n_attr, const int64_t* action,
+                    const float* reward, const float* done, float* mse_part, float* dq, int B, int T,
+                    int NA, int64_t ld, float gamma, void* stream);
+/* scatter dq into the gradient rows of batch element 0 of y (dy zero-filled by the caller), times *gout */
+int cwlt_dqn_td_bwd(const float* dq, const int64_t* action, const int* n_class, int n_attr, float* dy,
+                    const float* gout, int B, int NA, int64_t ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

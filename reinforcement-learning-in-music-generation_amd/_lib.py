@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -43,6 +43,13 @@ _SIGNATURES = {
     "cwlt_heads_blocks": [_c_i64],
     "cwlt_heads_fwd": [_ptr, _ptr, _c_int] + [_ptr] * 7 + [_c_i64, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_heads_ce_bwd": [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_heads_logp_bwd": [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_rollout_gather": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64, _c_int, _ptr],
+    "cwlt_ppo_returns_adv": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_f32, _c_int, _ptr],
+    "cwlt_ppo_policy_loss": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_f32, _ptr],
+    "cwlt_dqn_td_fwd": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_i64,
+                        _c_f32, _ptr],
+    "cwlt_dqn_td_bwd": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _c_int, _c_int, _c_i64, _ptr],
 }
 
 _lib = None

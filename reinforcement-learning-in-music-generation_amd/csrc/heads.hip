@@ -119,7 +119,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void heads_ce_bwd_kernel(const T* __restrict__ logits, HeadArgs a,
                                                            const int64_t* __restrict__ target,
                                                            const float* __restrict__ mask,
-                                                           const float* __restrict__ coef, T* __restrict__ dlogits,
+                                                           const float* __restrict__ coef,
+                                                           const float* __restrict__ wrf, T* __restrict__ dlogits,
                                                            long rows, long ld, int ncols_total) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int used = 0;
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256) void heads_ce_bwd_kernel(const T* __restrict__
             const Seg s = load_seg(row, off, n, lane);
             long t = target[r * a.n_attr + f];
             t = t < 0 ? 0 : (t >= n ? n - 1 : t);
-            const float w = mk * coef[f];
+            const float w = wrf ? wrf[r * a.n_attr + f] : mk * coef[f];   // per-(row, attribute) weight or mask*coef
             const float inv = 1.0f / s.sum;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -223,10 +224,37 @@ int cwlt_heads_ce_bwd(const void* logits, const int* n_class, int n_attr, const 
     const int nb = cwlt_heads_blocks(rows);
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((heads_ce_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)logits, a, target,
-                           mask, coef, (float*)dlogits, (long)rows, (long)ld, (int)ld);
+                           mask, coef, (const float*)nullptr, (float*)dlogits, (long)rows, (long)ld, (int)ld);
     else if (dtype == CWLT_BF16)
         hipLaunchKernelGGL((heads_ce_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)logits, a, target,
-                           mask, coef, (bf16_t*)dlogits, (long)rows, (long)ld, (int)ld);
+                           mask, coef, (const float*)nullptr, (bf16_t*)dlogits, (long)rows, (long)ld, (int)ld);
+    else
+        return CWLT_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+/* Gradient of sum_{r,f} g[r][f] * log softmax_f(logits_r)[target[r][f]]:
+ * dlogits[r, seg f] = (onehot(target) - softmax) * g[r][f];  g (rows, n_attr) f32 on device. */
+int cwlt_heads_logp_bwd(const void* logits, const int* n_class, int n_attr, const int64_t* target, const float* g,
+                        void* dlogits, int64_t rows, int64_t ld, int dtype, void* stream) {
+    using namespace cwlt;
+    HeadArgs a;
+    int e = fill_heads(a, n_class, n_attr);
+    if (e) return e;
+    const int used = a.off[n_attr - 1] + a.n[n_attr - 1];
+    if (!logits || !target || !g || !dlogits || rows < 0 || ld < used) return CWLT_ERR_ARG;
+    if (rows == 0) return CWLT_OK;
+    hipStream_t st = (hipStream_t)stream;
+    const int nb = cwlt_heads_blocks(rows);
+    // the kernel computes (softmax - onehot) * w; the caller passes w = -g through `neg`
+    if (dtype == CWLT_F32)
+        hipLaunchKernelGGL((heads_ce_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)logits, a, target,
+                           (const float*)nullptr, (const float*)nullptr, g, (float*)dlogits, (long)rows, (long)ld,
+                           (int)ld);
+    else if (dtype == CWLT_BF16)
+        hipLaunchKernelGGL((heads_ce_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)logits, a, target,
+                           (const float*)nullptr, (const float*)nullptr, g, (bf16_t*)dlogits, (long)rows, (long)ld,
+                           (int)ld);
     else
         return CWLT_ERR_DTYPE;
     return (int)hipGetLastError();
