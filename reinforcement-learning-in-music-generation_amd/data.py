@@ -1,0 +1,58 @@
+"""Dataset plumbing for the entry scripts: the reference's on-disk formats when the files exist, synthetic
+data of the same schema otherwise (the dataset and the pretrained weights are external downloads,
+README.md:23,27 -- unavailable offline).
+
+  dqn: train_data_linear.npz {x, y (N, 3584, 7) int, mask (N, 3584)} + dictionary.pkl = (event2word, word2event)
+       keyed tempo, chord, bar-beat, type, pitch, duration, velocity      (IRL_dqn_train.py:389-391,418-420)
+  ppo: dictionary.pickle + our_dataset.pickle {train_x, train_y (N, 1200, 6), mask (N, 1200)}
+       (ppo_train.py:432-449, preprocess.py:66-72)
+"""
+import os
+import pickle
+
+import numpy as np
+
+DQN_KEYS = ("tempo", "chord", "bar-beat", "type", "pitch", "duration", "velocity")
+DQN_N = (56, 135, 18, 3, 87, 18, 25)             # IRL_dqn_train.py:403 (+ 3 `type` classes)
+PPO_KEYS = ("tempo", "bar", "position", "pitch", "duration", "velocity")
+PPO_N = (49, 19, 19, 89, 67, 25)                 # prepare_data.py:247-291
+
+
+def _synth(n_seq, T, n_per_field, seed):
+    rng = np.random.default_rng(seed)
+    x = np.stack([rng.integers(0, n, (n_seq, T)) for n in n_per_field], -1).astype(np.int64)
+    y = np.stack([rng.integers(0, n, (n_seq, T)) for n in n_per_field], -1).astype(np.int64)
+    mask = np.ones((n_seq, T), dtype=np.float32)
+    mask[: n_seq // 2, int(T * 0.9):] = 0
+    return x, y, mask
+
+
+def load_dqn(path_train_data, path_dictionary, n_seq=8, T=3584, seed=1234):
+    """-> (event2word, word2event), {x, y, mask}; synthetic when the files are absent."""
+    if os.path.exists(path_train_data) and os.path.exists(path_dictionary):
+        with open(path_dictionary, "rb") as f:
+            dictionary = pickle.load(f)
+        d = np.load(path_train_data)
+        return dictionary, {"x": d["x"], "y": d["y"], "mask": d["mask"]}
+    print("[data] %s not found: using synthetic CW tokens of the same schema" % path_train_data)
+    e2w = {k: {"%s_%d" % (k, i): i for i in range(n)} for k, n in zip(DQN_KEYS, DQN_N)}
+    w2e = {k: {i: e for e, i in v.items()} for k, v in e2w.items()}
+    x, y, mask = _synth(n_seq, T, DQN_N, seed)
+    return (e2w, w2e), {"x": x, "y": y, "mask": mask}
+
+
+def load_ppo(path_dictionary, path_train_data, n_seq=8, T=1200, seed=1234):
+    if os.path.exists(path_train_data) and os.path.exists(path_dictionary):
+        with open(path_dictionary, "rb") as f:
+            dictionary = pickle.load(f)
+        with open(path_train_data, "rb") as f:
+            ds = pickle.load(f)
+        return dictionary, ds
+    print("[data] %s not found: using synthetic CW tokens of the same schema" % path_train_data)
+    e2w = {k: {"%s_%d" % (k, i): i for i in range(n)} for k, n in zip(PPO_KEYS, PPO_N)}
+    w2e = {k: {i: e for e, i in v.items()} for k, v in e2w.items()}
+    x, y, mask = _synth(n_seq, T, PPO_N, seed)
+    return (e2w, w2e), {"train_x": x, "train_y": y, "mask": mask}
+
+
+_orig_load_dqn = load_dqn

@@ -1,0 +1,98 @@
+"""Drop-in for /root/reference/dqn_policy/AIRL.py: `RewardDiscri`, the AIRL reward module around the
+Longformer discriminator.  Scoring (`all_forward`, `calculate_reward`, `update_disc(train=False)`) runs
+on the libcwlt kernels; that is the only mode the RL loop uses (IRL_dqn_train.py:477).  The training
+branch (`train=True`, AIRL.py:135-212) needs the discriminator backward, which is the next widening step
+ and raises NotImplementedError here.
+"""
+import os
+import pickle
+import sys
+
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+import rlmg_amd  # noqa: E402,F401
+
+try:
+    from AIRL_model import LongFormer
+except ImportError:
+    from .AIRL_model import LongFormer
+
+MAX_SEQ_LEN = 1024
+D_MODEL = 512
+N_LAYER = 10
+N_HEAD = 8
+path_exp = "exp"
+N_STATES = 50
+Pretrain_ckpt = "/data/Der_CODES/DQN-cp/ckpt/trainloss_22.pt"
+
+
+class RewardDiscri(nn.Module):
+    def __init__(self, n_token, Pretrain=True):
+        super().__init__()
+        self.disc_model = LongFormer(n_token).cuda()
+        if Pretrain:
+            checkpoint = torch.load(Pretrain_ckpt)
+            self.disc_model.load_state_dict(checkpoint["model_state_dict"])
+        self.BCE_criterion = nn.BCELoss()
+        self.CrossEntropy = nn.CrossEntropyLoss()
+        self.avg_score = nn.Sequential(nn.Linear(6, 1).cuda(), nn.Sigmoid())     # declared, unused (AIRL.py:45-49)
+        self.last_unit = nn.Linear(6, 1).cuda()
+        self.init_lr = 0.001
+        self.epoch_disc = 5
+        self.batch_size = 100
+        self.optim_disc = optim.Adam(self.disc_model.parameters(), lr=self.init_lr)
+        self.sched_disc = torch.optim.lr_scheduler.StepLR(self.optim_disc, step_size=10, gamma=0.1)
+        self.reward_path = "./exp/IRL_reward.pickle"
+        self.IRL_ckpt_path = "./ckpt/disc_IRL.pt"
+        self._ckpt_mtime = None
+
+    def all_forward(self, states_batch, dones_batch, next_states_batch, mask_states_batch, mask_next_states_batch):
+        """AIRL.py:61-65 -- forces train() (dropout + BatchNorm batch statistics live even while scoring)."""
+        self.disc_model.train()
+        return self.disc_model(states_batch, mask_states_batch)
+
+    def _maybe_reload(self):
+        """The reference re-reads ./ckpt/disc_IRL.pt from disk on EVERY call (AIRL.py:73); here the file is
+        re-read only when it changed.  A missing file keeps the current weights (the reference would raise)."""
+        p = self.IRL_ckpt_path
+        if os.path.exists(p):
+            m = os.path.getmtime(p)
+            if m != self._ckpt_mtime:
+                self.disc_model.load_state_dict(torch.load(p)["model_state_dict"])
+                self._ckpt_mtime = m
+
+    def calculate_reward(self, states, dones, next_states, mask_states, mask_next_states):
+        """AIRL.py:69-91: score the whole buffer in batches of 100; a tail shorter than 100 keeps 1.0."""
+        n = states.shape[0]
+        pred_val = torch.ones((n, 1))
+        self._maybe_reload()
+        self.disc_model.eval()
+        with torch.no_grad():
+            for idx in range(n // self.batch_size):
+                s, e = idx * self.batch_size, (idx + 1) * self.batch_size
+                score = self.all_forward(states[s:e].long().cuda(), dones[s:e].long().cuda(),
+                                         next_states[s:e].long().cuda(), mask_states[s:e].long().cuda(),
+                                         mask_next_states[s:e].long().cuda())
+                pred_val[s:e] = score.float().cpu()
+        return pred_val
+
+    def update_disc(self, agent_episode, expert_episode, train=True):
+        """AIRL.py:121-236 with train=False: rewards of the agent and expert buffers + the reward pickle."""
+        if train:
+            raise NotImplementedError("discriminator training (AIRL.py:135-212) needs the Longformer backward: "
+                                      "next widening step (SURVEY §8f #3); the RL loop calls train=False")
+        agent_state_action, _, _, agent_nextstate_action, agent_done = agent_episode
+        exp_state_action, _, _, exp_nextstate_action, exp_done, mask_states, mask_next_states = expert_episode
+        traj_reward = self.calculate_reward(agent_state_action, agent_done, agent_nextstate_action, mask_states,
+                                            mask_next_states)
+        answer_reward = self.calculate_reward(exp_state_action, exp_done, exp_nextstate_action, mask_states,
+                                              mask_next_states)
+        os.makedirs(os.path.dirname(self.reward_path), exist_ok=True)
+        with open(self.reward_path, "wb") as f:
+            pickle.dump({"Agent": traj_reward, "Expert": answer_reward}, f)
+        return traj_reward, answer_reward

@@ -1,0 +1,108 @@
+"""Drop-in for /root/reference/dqn_policy/agent_pretrain.py (MODE='train'): `TransformerModel`
+(the same network as model.LinearTransformer) and `train()`.  `generate()` / `write_midi` (MIDI output,
+needs miditoolkit) are outside the hot path -- SURVEY §2a marks them OUT OF SCOPE.
+"""
+import datetime
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import data as cwdata, dist as rdist  # noqa: E402
+
+try:
+    from model import LinearTransformer, network_paras
+except ImportError:
+    from .model import LinearTransformer, network_paras
+
+MODE = "train"
+path_data_root = "/data/dataset_Pop1K7/representations/uncond/cp/ailab17k_from-scratch_cp"
+path_train_data = os.path.join(path_data_root, "train_data_linear.npz")
+path_dictionary = os.path.join(path_data_root, "dictionary.pkl")
+D_MODEL, N_LAYER, N_HEAD = 512, 12, 8
+path_exp = "exp"
+batch_size = 4
+gid = 0
+init_lr = 0.0001
+
+
+class TransformerModel(LinearTransformer):
+    """agent_pretrain.py:213 re-declares model.LinearTransformer under this name."""
+
+
+def train(n_epoch=None, compute_dtype=torch.float32, log=print):
+    """agent_pretrain.py:485-632: sequential batches of 4, loss = mean of the 6 CE losses, zero_grad / backward /
+    clip_grad_norm_(3) / Adam(1e-4); loss-banded checkpoints under ./ckpt."""
+    n_epoch = int(os.environ.get("CWLT_N_EPOCH", 4000)) if n_epoch is None else n_epoch
+    max_grad_norm = 3
+    rank, local, world = rdist.init_from_env()
+    torch.cuda.set_device(local)
+    dictionary, train_data = cwdata.load_dqn(path_train_data, path_dictionary)
+    event2word, word2event = dictionary
+    n_class = [len(event2word[k]) for k in event2word.keys() if k != "type"]
+    log("num of classes:", n_class)
+    net = TransformerModel(n_class)
+    net.cuda()
+    net.train()
+    net.compute_dtype = compute_dtype
+    log("n_parameters: {:,}".format(network_paras(net)))
+    sync = rdist.GradSync(net.parameters())
+    optimizer = optim.Adam(net.parameters(), lr=init_lr)
+    train_x = np.concatenate((train_data["x"][:, :, :3], train_data["x"][:, :, 4:]), axis=2)
+    train_y = np.concatenate((train_data["y"][:, :, :3], train_data["y"][:, :, 4:]), axis=2)
+    train_mask = train_data["mask"]
+    num_batch = len(train_x) // (batch_size * world)
+    start_time = time.time()
+    epoch_loss = float("nan")
+    for epoch in range(n_epoch):
+        acc_loss, acc_losses = 0.0, np.zeros(6)
+        for bidx in range(num_batch):
+            st = batch_size * (bidx * world + rank)              # rank-strided batches under data parallelism
+            batch_x = torch.from_numpy(train_x[st:st + batch_size]).long().cuda()
+            batch_y = torch.from_numpy(train_y[st:st + batch_size]).long().cuda()
+            batch_mask = torch.from_numpy(train_mask[st:st + batch_size]).float().cuda()
+            losses = net.train_step(batch_x, batch_y, batch_mask)
+            loss = (losses[0] + losses[1] + losses[2] + losses[3] + losses[4] + losses[5]) / 6
+            sync.zero_grad()
+            loss.backward()
+            sync.finish()
+            sync.clip_grad_norm_(max_grad_norm)
+            optimizer.step()
+            acc_losses += np.array([l.item() for l in losses])
+            acc_loss += loss.item()
+        runtime = time.time() - start_time
+        epoch_loss = acc_loss / max(1, num_batch)
+        log("Epoch: {}/{} | Loss: {} | time: {}".format(epoch, n_epoch, epoch_loss,
+                                                        str(datetime.timedelta(seconds=runtime))))
+        if rank == 0:
+            os.makedirs("./ckpt", exist_ok=True)
+            if 0.4 < epoch_loss <= 0.8:
+                name = "trainloss_" + str(int(epoch_loss * 10) * 10) + ".pt"
+            elif 0.05 < epoch_loss <= 0.40:
+                name = "trainloss_" + str(int(epoch_loss * 100)) + ".pt"
+            elif epoch_loss <= 0.05:
+                log("Finished")
+                return epoch_loss
+            else:
+                name = "trainloss_" + str(int(epoch_loss * 100)) + "_high.pt"
+            torch.save({"epoch": n_epoch, "model_state_dict": net.state_dict(),
+                        "optimizer_state_dict": optimizer.state_dict()}, os.path.join("./ckpt", name))
+    return epoch_loss
+
+
+def generate():
+    raise NotImplementedError("generation / MIDI writing is outside the training hot path (SURVEY §2a, §8f #1)")
+
+
+if __name__ == "__main__":
+    if MODE == "train":
+        train()
+    elif MODE == "inference":
+        generate()
