@@ -1,0 +1,154 @@
+#!/usr/bin/env python3
+"""PPO + IRL fine-tuning throughput (BASELINE.json configs[2]: R parallel rollouts, window W).
+
+    python bench_ppo.py --gpus N --rollouts 64 --window 1024 --iters K --warmup W
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench_ppo.py --gpus N ...)
+
+One iteration = the body of the reference's outer loop (ppo_policy/ppo_train.py:460-506), generalised from
+one rollout to R rollouts per GPU run in lock-step:
+  rollout phase, EPISODES steps:  actor greedy forward on (R, W, 6) -> action / log-prob rows (reference
+      indexing incl. its quirks) -> next state = first half of the old window + the W/2 action tokens ->
+      critic value -> reward model (Longformer, band attention) -> GPU-resident buffer write
+  update phase, PPO_STEPS inner steps: per rollout, `select_udpate` on its (EPISODES, W, 6) states, ratio-clip
+      surrogate + CE vs the expert windows, critic MSE; gradients accumulated over the R rollouts, one Adam step
+      per net per inner step (data-parallel all-reduce across GPUs when N > 1).
+env-step = one (rollout, step) pair.  Prints one JSON line: whole-iteration and rollout-only
+env-steps/s.  bf16 activations, dropout live (the reference trains with nets in train() mode).
+"""
+import argparse
+import contextlib
+import io
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def log(msg):
+    print("[bench_ppo] " + msg, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--rollouts", type=int, default=64, help="parallel rollouts per GPU")
+    ap.add_argument("--window", type=int, default=1024)
+    ap.add_argument("--episodes", type=int, default=30)
+    ap.add_argument("--ppo-steps", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    args = ap.parse_args()
+
+    import rlmg_amd  # noqa: F401
+    from rlmg_amd import dist as rdist, gemm_tuning, ops, rl_ops
+    from rlmg_amd.ppo_policy import ppo_train as P
+
+    rank, local, world = rdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    gemm_tuning.enable()
+    R, W, E = args.rollouts, args.window, args.episodes
+    NA = W // 2
+    P.N_ACTIONS = P.NUM_ACTION = NA
+    P.N_STATES = P.WINDOW_SIZE = W
+    n_token = [49, 19, 19, 89, 67, 25]
+    torch.manual_seed(0)
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = P.PPO(n_token, Pretrain=False)
+    adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    for net in (agent.actor_net, agent.critic_net, agent.eval_net):
+        net.compute_dtype = adt
+    g = torch.Generator().manual_seed(1234 + rank)
+    expert = torch.stack([torch.randint(0, n, (R, W + E + W), generator=g) for n in n_token], -1).to(dev)
+    mask = torch.ones(R, W + E + W, device=dev)
+    torch.manual_seed(100 + rank)
+
+    def iteration():
+        t_roll0 = time.perf_counter()
+        state = expert[:, :W].clone()
+        states = torch.empty((E, R, W, 6), dtype=torch.int64, device=dev)
+        logps = torch.empty((E, R, NA, 6), dtype=torch.float32, device=dev)
+        values = torch.empty((E, R), dtype=torch.float32, device=dev)
+        rewards = torch.empty((E, R), dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for t in range(E):
+                action, logp = agent.choose_action(state)                       # (R, NA, 6)
+                if R == 1:
+                    action, logp = action.unsqueeze(0), logp.unsqueeze(0)
+                state = torch.cat((state[:, :NA], action), dim=1)               # next_state (ppo_train.py:483)
+                values[t] = agent.critic_net.value_produce(state).reshape(R)
+                rewards[t] = agent.eval_net.token_forward(state, None, mask[:, t:t + W]).reshape(R)
+                states[t], logps[t] = state, logp
+        torch.cuda.synchronize()
+        t_roll = time.perf_counter() - t_roll0
+        old_int = logps.long()                                                  # buffer returns .long() (:122,135)
+        rets, advs = [], []
+        for r in range(R):
+            ret, adv = rl_ops.ppo_returns_adv(rewards[:, r], values[:, r], P.DISCOUNT_FACTOR, True)
+            rets.append(ret)
+            advs.append(adv)
+        for _ in range(args.ppo_steps):
+            agent.actor_sync.zero_grad()
+            agent.critic_sync.zero_grad()
+            for r in range(R):                                                  # gradient accumulation over rollouts
+                st = states[:, r]
+                _, new_logp, value_pred = agent.select_udpate(st)
+                pl = rl_ops.ppo_policy_loss(new_logp, old_int[:, r], advs[r], P.PPO_CLIP)
+                ce = agent.actor_net.train_step(st, expert[r, :E + W].unfold(0, W, 1)[:E].permute(0, 2, 1),
+                                                mask[r, :E + W].unfold(0, W, 1)[:E])
+                actor_loss = (pl + (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6) / R
+                actor_loss.backward()
+                (torch.nn.functional.mse_loss(rets[r], value_pred).sum() / R).backward()
+            agent.actor_sync.finish()
+            agent.critic_sync.finish()
+            agent.actor_optim.step()
+            agent.critic_optim.step()
+        return t_roll
+
+    def fence():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        iteration()
+        log("warm-up iteration %d done" % i)
+    fence()
+    t0 = time.perf_counter()
+    t_roll = 0.0
+    for i in range(args.iters):
+        t_roll += iteration()
+        log("iteration %d done" % i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt, t_roll], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt, t_roll = t.tolist()
+    if rank == 0:
+        steps = world * R * E * args.iters
+        print(json.dumps({
+            "metric": "PPO env-steps/sec", "value": round(steps / dt, 2), "unit": "env-steps/s", "n_gpus": world,
+            "steps": args.iters, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.iters, 1),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "rollout_only_env_steps_per_s": round(steps / t_roll, 2),
+            "config": {"workload": "ppo_train iteration: %d rollouts/GPU x window %d, EPISODES %d, PPO_STEPS %d, "
+                                   "actor/critic 512/12/8, reward Longformer 512/12/8 w=512" % (R, W, E, args.ppo_steps),
+                       "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
+                       "parallelism": "dp%d" % world}}), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
