@@ -59,6 +59,14 @@ def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
     }.get(entry)
 
 
+def algorithmic_flops(entry, B, T, D=512, F=2048):
+    """MFMA-bound entry points: FLOPs of ONE launch (mean over the shapes it is called with per layer)."""
+    R = B * T
+    if entry == "cwlt_wgrad_bf16":     # dW2 (D x F), dW1 (F x D), dWo (D x D), dWqkv (3D x D)
+        return 2.0 * R * (2 * D * F + D * D + 3 * D * D) / 4
+    return None
+
+
 def usable_cores():
     """CPU threads this process may really use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -203,10 +211,16 @@ def main():
             tot = {k: c * m for k, (c, m) in kt.items()}
             for k, (c, m) in sorted(kt.items(), key=lambda kv: -tot[kv[0]]):
                 ab = algorithmic_bytes(k, B, T, s=s)
+                fl = algorithmic_flops(k, B, T)
                 kernels[k] = {"calls_per_step": c / args.steps, "avg_ms": round(m, 4),
                               "share_of_step": round(tot[k] / (dt * 1e3), 4),
                               "GB/s": round(ab / (m * 1e-3) / 1e9, 1) if ab else None}
-            dom = max(tot, key=tot.get)
+                if fl:
+                    kernels[k]["TFLOP/s"] = round(fl / (m * 1e-3) / 1e12, 1)
+            # roofline: the HBM-bound libcwlt entry point with the largest total time (the MFMA-bound
+            # weight-gradient GEMM is reported alongside in `kernels` and `roofline_mfma`)
+            hbm = {k: v for k, v in tot.items() if algorithmic_bytes(k, B, T, s=s)}
+            dom = max(hbm, key=hbm.get)
             ab = algorithmic_bytes(dom, B, T, s=s)
             ach = ab / (kt[dom][1] * 1e-3) / 1e9
             traffic = None
@@ -231,6 +245,12 @@ def main():
             "model_mfma_frac": round(tokens_per_s / world * FLOP_PER_TOKEN / MFMA_BF16_PEAK, 4),
             "roofline": roofline, "kernels": kernels,
         }
+        if "cwlt_wgrad_bf16" in kt:
+            fl = algorithmic_flops("cwlt_wgrad_bf16", B, T)
+            ach_tf = fl / (kt["cwlt_wgrad_bf16"][1] * 1e-3) / 1e12
+            out["roofline_mfma"] = {"kernel": "cwlt_wgrad_bf16", "bound": "mfma", "achieved": round(ach_tf, 1),
+                                    "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
+                                    "frac": round(ach_tf * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             out["cpu_baseline"] = cb

@@ -191,6 +191,15 @@ int cwlt_dqn_td_fwd(const float* y, const float* yt, const int* n_class, int n_a
 int cwlt_dqn_td_bwd(const float* dq, const int64_t* action, const int* n_class, int n_attr, float* dy,
                     const float* gout, int B, int NA, int64_t ld, void* stream);
 
+/* ---- weight-gradient GEMM of the dense projections ------------------------------------------------
+ * out (N1, N2) f32 (+)= A^T B with A = upstream gradient (M, N1), B = layer input (M, N2), bf16 row-major,
+ * M = B*T token rows (the reduction).  Replaces the weight-gradient GEMMs autograd runs for the nn.Linear
+ * layers of the encoder (dqn_policy/model.py:128-137; FT AttentionLayer / TransformerEncoderLayer).
+ * N1, N2 multiples of 256; part: cwlt_wgrad_splits(M, N1, N2) * N1 * N2 f32.  Deterministic. */
+int cwlt_wgrad_splits(int64_t M, int N1, int N2);
+int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64_t M, int N1, int N2,
+                    int64_t lda, int64_t ldb, int accumulate, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

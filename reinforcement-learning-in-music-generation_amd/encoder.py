@@ -32,7 +32,7 @@ class _EncoderLayerFn(torch.autograd.Function):
     CausalLinearAttention), x: (N, L, D) -> (N, L, D)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, H, p, seeds):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, H, p, seeds, layer):
         N, L, D = x.shape
         R = N * L
         adt = x.dtype
@@ -58,6 +58,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2,
                               wqkv, wo_a, w1_a, w2_a, g1f, g2f, b1f)
         ctx.cfg = (N, L, D, H, p, seeds)
+        ctx.layer = layer
         return out.view(N, L, D)
 
     @staticmethod
@@ -68,27 +69,49 @@ class _EncoderLayerFn(torch.autograd.Function):
         R = N * L
         dout2 = dout.reshape(R, D)
 
+        # weight gradients: hand-written split-K MFMA GEMM (f32 result) in bf16 mode, hipBLASLt otherwise
+        def wgrad(a_, b_):
+            if ops.wgrad_supported(a_, b_):
+                return ops.wgrad(a_, b_)
+            return torch.mm(a_.t(), b_)
+
         ds2, dy, dg2, dbe2, db2 = ops.ln_bwd(dout2, None, s2, g2f, mean2, rstd2, p, seeds[2])
         dgact = torch.mm(dy, w2_a)                                         # (R, F)
-        dw2 = torch.mm(dy.t(), g)                                          # (D, F)
+        dw2 = wgrad(dy, g)                                                 # (D, F)
         dh, db1 = ops.gelu_bwd(dgact, h, b1f, p, seeds[1])
         del dgact
         dx1 = torch.mm(dh, w1_a)                                           # (R, D)
-        dw1 = torch.mm(dh.t(), x1)                                         # (F, D)
+        dw1 = wgrad(dh, x1)                                                # (F, D)
         del dh
         ds1, do, dg1, dbe1, dbo = ops.ln_bwd(ds2, dx1, s1, g1f, mean1, rstd1, p, seeds[0])
         da = torch.mm(do, wo_a)                                            # (R, D)
-        dwo = torch.mm(do.t(), a.view(R, D))
+        dwo = wgrad(do, a.view(R, D))
         qkv5 = qkv.view(N, L, 3, H, D // H)
         dqkv = ops.cla_bwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2], a, zinv, da.view(N, L, H, D // H))
         dqkv2 = dqkv.view(R, 3 * D)
         dx = torch.addmm(ds1, dqkv2, wqkv)                                 # residual + projection gradient
-        dwqkv = torch.mm(dqkv2.t(), x2).float()                            # (3D, D)
+        dwqkv = wgrad(dqkv2, x2)                                           # (3D, D)
         dbqkv = ops.colsum(dqkv2)
+        layer = ctx.layer
+        if layer is not None and ops.direct_grads():
+            # single process: write the 16 parameter gradients straight into .grad (flat f32 buckets),
+            # one fused convert+store each, instead of .float() + autograd's accumulate
+            at = layer.attention
+            for prm, g in ((at.query_projection.weight, dwqkv[:D]), (at.query_projection.bias, dbqkv[:D]),
+                           (at.key_projection.weight, dwqkv[D:2 * D]), (at.key_projection.bias, dbqkv[D:2 * D]),
+                           (at.value_projection.weight, dwqkv[2 * D:]), (at.value_projection.bias, dbqkv[2 * D:]),
+                           (at.out_projection.weight, dwo), (at.out_projection.bias, dbo),
+                           (layer.linear1.weight, dw1), (layer.linear1.bias, db1),
+                           (layer.linear2.weight, dw2), (layer.linear2.bias, db2),
+                           (layer.norm1.weight, dg1), (layer.norm1.bias, dbe1),
+                           (layer.norm2.weight, dg2), (layer.norm2.bias, dbe2)):
+                ops.deliver_grad(prm, g)
+            return (dx.view(N, L, D),) + (None,) * 20
+        dwqkv = dwqkv.float()
         return (dx.view(N, L, D),
                 dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
                 dwo.float(), dbo, dw1.float(), db1, dw2.float(), db2, dg1, dbe1, dg2, dbe2,
-                None, None, None)
+                None, None, None, None)
 
 
 class AttentionLayer(nn.Module):
@@ -123,7 +146,7 @@ class TransformerEncoderLayer(nn.Module):
             x, at.query_projection.weight, at.query_projection.bias, at.key_projection.weight, at.key_projection.bias,
             at.value_projection.weight, at.value_projection.bias, at.out_projection.weight, at.out_projection.bias,
             self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-            self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, at.n_heads, p, seeds)
+            self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, at.n_heads, p, seeds, self)
 
 
 class TransformerEncoder(nn.Module):

@@ -79,6 +79,27 @@ def _call(name, *args):
     _lib.check(st, name)
 
 
+def direct_grads():
+    """True when parameter gradients may be written straight into .grad by the layer backward (single
+    process).  Under data parallelism gradients go through autograd so that GradSync's post-accumulate
+    hooks see each parameter exactly once per backward."""
+    import torch.distributed as dist
+    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+
+
+def deliver_grad(p, g):
+    """p.grad (+)= g with one fused convert+store (g may be bf16, p.grad is f32)."""
+    if not p.requires_grad:
+        return
+    if p.grad is None:
+        p.grad = g.float().clone() if g.dtype == torch.float32 else g.float()
+    elif getattr(p, "_cwlt_fresh", False):
+        p.grad.copy_(g)
+        p._cwlt_fresh = False
+    else:
+        p.grad.add_(g)
+
+
 _seed_counter = [0]
 
 
@@ -241,6 +262,28 @@ def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
                                               _lib.opt(part), _lib.opt(dbias), rows, F, float(p), int(seed),
                                               _lib.dtype_code(h.dtype), _lib.stream_ptr())
     return dh, dbias
+
+
+def wgrad_supported(a, b):
+    return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
+            and a.shape[1] % 256 == 0 and b.shape[1] % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1
+            and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def wgrad(a, b, out=None, accumulate=False):
+    """out (N1, N2) f32 (+)= a^T b;  a (M, N1), b (M, N2) bf16 row-major.  The weight gradient of a Linear with
+    input b and output gradient a.  `out` may be a dense f32 .grad view (written in place)."""
+    lib = _lib.load()
+    M, N1 = a.shape
+    N2 = b.shape[1]
+    S = lib.cwlt_wgrad_splits(M, N1, N2)
+    part = torch.empty(S * N1 * N2, dtype=torch.float32, device=a.device)
+    if out is None:
+        out = torch.empty((N1, N2), dtype=torch.float32, device=a.device)
+        accumulate = False
+    _call("cwlt_wgrad_bf16", _lib.dev(a, "a"), _lib.dev(b, "b"), _lib.dev(part), _lib.dev(out), M, N1, N2,
+          a.stride(0), b.stride(0), 1 if accumulate else 0, _lib.stream_ptr())
+    return out
 
 
 def colsum(x):

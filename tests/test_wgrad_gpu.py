@@ -1,0 +1,33 @@
+"""GPU: the split-K MFMA weight-gradient GEMM vs an fp64 reference."""
+import pytest
+import torch
+
+import rlmg_amd  # noqa: F401
+from rlmg_amd import ops
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("M,N1,N2", [(32, 256, 256), (1000, 512, 256), (4096, 2048, 512), (777, 256, 1536)])
+def test_wgrad_matches_fp64(cuda, M, N1, N2):
+    g = torch.Generator().manual_seed(M)
+    a = torch.randn(M, N1, generator=g).bfloat16()
+    b = torch.randn(M, N2, generator=g).bfloat16()
+    ref = a.double().t() @ b.double()
+    got = ops.wgrad(a.to(cuda), b.to(cuda))
+    err = (got.cpu().double() - ref).abs().max().item()
+    assert err <= 1e-4 * max(1.0, ref.abs().max().item()), err       # f32 accumulation of exact bf16 products
+    acc = torch.ones(N1, N2, device=cuda)
+    ops.wgrad(a.to(cuda), b.to(cuda), out=acc, accumulate=True)
+    assert (acc.cpu().double() - (ref + 1)).abs().max().item() <= 1e-4 * max(1.0, ref.abs().max().item())
+
+
+def test_wgrad_strided_operands_and_determinism(cuda):
+    big = torch.randn(3000, 3, 512, device=cuda).bfloat16()
+    x = torch.randn(3000, 512, device=cuda).bfloat16()
+    a = big.view(3000, 1536)
+    r1 = ops.wgrad(a, x)
+    r2 = ops.wgrad(a, x)
+    assert torch.equal(r1, r2)
+    ref = a.double().t() @ x.double()
+    assert (r1.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()

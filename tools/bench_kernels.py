@@ -41,5 +41,21 @@ def main():
         print("%-8s cla_bwd   %8.1f us  %7.1f GB/s (algorithmic, 7 streams)" % (dt, t * 1e3, R * 7 * 512 * s / t / 1e6))
 
 
+def bench_wgrad():
+    dev = torch.device("cuda:0")
+    M = 65536
+    for N1, N2 in ((2048, 512), (512, 2048), (512, 512), (1536, 512)):
+        a = torch.randn(M, N1, device=dev).bfloat16()
+        b = torch.randn(M, N2, device=dev).bfloat16()
+        t0 = timeit(lambda: torch.mm(a.t(), b))
+        t1 = timeit(lambda: ops.wgrad(a, b))
+        fl = 2.0 * M * N1 * N2
+        print("wgrad %4dx%4d  torch.mm %7.1f us (%6.0f TF)   cwlt %7.1f us (%6.0f TF)" %
+              (N1, N2, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
+        bench_wgrad()
+        sys.exit(0)
     main()
