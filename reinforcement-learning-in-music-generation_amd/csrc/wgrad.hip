@@ -46,8 +46,16 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 16 waves as 4 x 4, each 64 x 64
     const int wn1 = w >> 2, wn2 = w & 3;
     const int l31 = lane & 31, hf = lane >> 5;
-    const int t1 = blockIdx.x, t2 = blockIdx.y;
-    const long m0 = (long)blockIdx.z * mslice;
+    // XCD-aware work mapping (speed only): workgroup ids are dealt round-robin over the 8 XCDs, so id % 8
+    // labels the XCD.  All tiles of one token slice read the same A / B rows; giving a slice's tiles to ONE
+    // XCD lets those re-reads hit that XCD's L2 instead of HBM.  S (number of slices) is a multiple of 8.
+    const int ntile = (N1 / TM) * (N2 / TN);
+    const int id = blockIdx.x;
+    const int xcd = id & 7, idx = id >> 3;
+    const int slice = xcd + 8 * (idx / ntile);
+    const int tile = idx % ntile;
+    const int t1 = tile / (N2 / TN), t2 = tile % (N2 / TN);
+    const long m0 = (long)slice * mslice;
     const long m1 = min(M, m0 + mslice);
     const bf16_t* Ab = A + (long)t1 * TM;
     const bf16_t* Bb = B + (long)t2 * TN;
@@ -91,35 +99,25 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     WG_STAGE(ra0, rb0, 0);
     WG_LOAD(ra0, rb0, m0 + BK);
     __syncthreads();
-    // steady state: compute LDS[cur]; loads for step+2 -> stage 1; stage 0 (step+1) -> LDS[cur^1]; rotate
-    int cur = 0;
-    for (long ms = m0; ms < m1; ms += BK) {
+    // steady state, unrolled by two so both register stages keep static names (a register rotation would
+    // make every iteration wait for its NEWEST loads); slices are padded to an even number of steps
+    // (rows past the slice end load zeros).
+    //   even step: compute LDS[0]; loads for step+2 -> stage 1; stage 0 (step+1) -> LDS[1]
+    //   odd  step: compute LDS[1]; loads for step+2 -> stage 0; stage 1 (step+1) -> LDS[0]
+    for (long ms = m0; ms < m1; ms += 2 * BK) {
         WG_LOAD(ra1, rb1, ms + 2 * BK);
-        const bf16_t* at = As[cur];
-        const bf16_t* bt = Bs[cur];
-#pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            bf16x8 a[2], b[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = tfrag(at, 16 * ks, 64 * wn1 + 32 * i, lane);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) b[j] = tfrag(bt, 16 * ks, 64 * wn2 + 32 * j, lane);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
-        }
-        WG_STAGE(ra0, rb0, cur ^ 1);
+        WG_COMPUTE(0);
+        WG_STAGE(ra0, rb0, 1);
         __syncthreads();
-        ra0 = ra1;
-        rb0 = rb1;
-        cur ^= 1;
+        WG_LOAD(ra0, rb0, ms + 3 * BK);
+        WG_COMPUTE(1);
+        WG_STAGE(ra1, rb1, 0);
+        __syncthreads();
     }
 #undef WG_LOAD
 #undef WG_STAGE
 #undef WG_COMPUTE
-    float* pb = part + ((long)blockIdx.z * N1 + (long)t1 * TM + 64 * wn1) * N2 + (long)t2 * TN + 64 * wn2 + l31;
+    float* pb = part + ((long)slice * N1 + (long)t1 * TM + 64 * wn1) * N2 + (long)t2 * TN + 64 * wn2 + l31;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -154,10 +152,9 @@ extern "C" {
 int cwlt_wgrad_splits(int64_t M, int N1, int N2) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 1;
     const long tiles = (long)(N1 / 256) * (N2 / 256);
-    long s = tiles > 0 ? 256 / tiles : 1;       // one 16-wave workgroup per CU
-    if (s < 1) s = 1;
-    const long maxs = (M + 255) / 256;          // at least 256 token rows per split
-    if (s > maxs) s = maxs;
+    long s = tiles > 0 ? 256 / tiles : 8;       // about one 16-wave workgroup per CU ...
+    s = s / 8 * 8;                              // ... in multiples of 8 (one slice group per XCD)
+    if (s < 8) s = 8;
     if (s > 128) s = 128;
     return (int)s;
 }
@@ -172,9 +169,9 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
         return CWLT_ERR_ARG;
     const int S = cwlt_wgrad_splits(M, N1, N2);
     long mslice = (M + S - 1) / S;
-    mslice = (mslice + wg::BK - 1) / wg::BK * wg::BK;
+    mslice = (mslice + 2 * wg::BK - 1) / (2 * wg::BK) * (2 * wg::BK);   // even number of BK steps
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wg::wgrad_kernel, dim3(N1 / 256, N2 / 256, S), dim3(1024), 0, st, (const bf16_t*)a,
+    hipLaunchKernelGGL(wg::wgrad_kernel, dim3((N1 / 256) * (N2 / 256) * S), dim3(1024), 0, st, (const bf16_t*)a,
                        (const bf16_t*)b, part, (long)M, N1, N2, (long)lda, (long)ldb, mslice);
     int e = (int)hipGetLastError();
     if (e) return e;
