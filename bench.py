@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="sequences per GPU")
+    ap.add_argument("--batch", type=int, default=256, help="sequences per GPU")
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
