@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
 //   R[e][m] = sum_{i later} qf_i[e] g_i[m],  r1[e] = sum_{i later} qf_i[e] dden_i
 // wave (wi, wj): W and A tiles (i-half wi, j-half wj); dk tile (j-half wi, e-half wj); dv tile (j-half wi, m-half wj).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void cla_bwd_dkdv_bf16_kernel(
+__global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo,
