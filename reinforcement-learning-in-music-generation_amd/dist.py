@@ -103,10 +103,14 @@ def init_from_env():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # test-only overrides: CWLT_DIST_BACKEND=gloo and CWLT_SINGLE_DEVICE=1 let several ranks share one GPU
+    # (RCCL refuses duplicate devices), to rehearse the multi-rank code path on a one-GPU box
+    if os.environ.get("CWLT_SINGLE_DEVICE") == "1":
+        local = 0
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
+        backend = os.environ.get("CWLT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local, world
