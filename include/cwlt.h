@@ -54,14 +54,18 @@ int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const vo
                            int64_t lddq, int64_t lddk, int64_t lddv, int dtype, void* stream);
 
 /* The two kernels of the backward, separately launchable (the call above = dkdv then dq):
- * reverse scan producing dk, dv; forward scan producing dq. */
+ * reverse scan producing dk, dv; forward scan producing dq.  colsum_* (each (N, H*head_dim) f32, may be
+ * NULL; bf16 tensors with row strides % 8 == 0 only): per-sequence column sums of the written gradient,
+ * i.e. the partial bias gradients of the key / value / query projections (summed over N by the caller),
+ * which saves a separate pass over dQ|dK|dV. */
 int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, const void* out,
                                 const float* zinv, const void* dout, void* dk, void* dv,
+                                float* colsum_k, float* colsum_v,
                                 int N, int H, int L, int head_dim,
                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                                 int64_t lddk, int64_t lddv, int dtype, void* stream);
 int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const void* out,
-                              const float* zinv, const void* dout, void* dq,
+                              const float* zinv, const void* dout, void* dq, float* colsum_q,
                               int N, int H, int L, int head_dim,
                               int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                               int64_t lddq, int dtype, void* stream);

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -25,8 +25,8 @@ _SIGNATURES = {
     "cwlt_causal_linear_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr],
     "cwlt_causal_linear_bwd": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
-    "cwlt_causal_linear_bwd_dkdv": [_ptr] * 8 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr],
-    "cwlt_causal_linear_bwd_dq": [_ptr] * 7 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr],
+    "cwlt_causal_linear_bwd_dkdv": [_ptr] * 10 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr],
+    "cwlt_causal_linear_bwd_dq": [_ptr] * 8 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr],
     "cwlt_ln_blocks": [_c_i64],
     "cwlt_add_dropout_layernorm_fwd": [_ptr] * 8 + [_c_i64, _c_int, _c_f32, _c_f32, _c_u64, _c_int, _ptr],
     "cwlt_add_dropout_layernorm_bwd": [_ptr] * 10 + [_c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],

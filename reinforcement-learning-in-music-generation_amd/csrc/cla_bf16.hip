@@ -314,6 +314,23 @@ __device__ __forceinline__ uint4 stage_g(uint4 rdo, uint4 ro, float z, float& dd
     return pack8(a);
 }
 
+// Per-stream column sums of a stored output: thread (row slot, 8-column slot) holds bsum[8]; reduce over
+// the 32 threads that share a column slot and write 64 floats.  `scratch` = any >= 256-float LDS area that
+// is no longer needed (called after the chunk loop).
+__device__ __forceinline__ void colsum_store(float (&bsum)[8], float* scratch, float* dst, int tid, int lane, int w) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float v = bsum[j];
+        v += __shfl_xor(v, 8, 64);
+        v += __shfl_xor(v, 16, 64);
+        v += __shfl_xor(v, 32, 64);
+        if ((lane >> 3) == 0) scratch[w * 64 + (lane & 7) * 8 + j] = v;
+    }
+    __syncthreads();
+    if (tid < 64) dst[tid] = (scratch[tid] + scratch[64 + tid]) + (scratch[128 + tid] + scratch[192 + tid]);
+}
+
 // ------------------------------------------------------------------------------------------------
 // backward, dQ (forward scan).  W_ij = g_i . v_j + dden_i (j <= i)
 //   dqf_i = sum_{j<=i} W_ij kf_j = (W kf)_i + S_prev g_i + dden_i ksum_prev ;  dQ = dqf * phi'(Q)
@@ -322,7 +339,8 @@ __device__ __forceinline__ uint4 stage_g(uint4 rdo, uint4 ro, float z, float& dd
 __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
-    bf16_t* __restrict__ dq, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddq) {
+    bf16_t* __restrict__ dq, float* __restrict__ csum, int H, int L, long ldq, long ldk, long ldv, long ldo,
+    long lddo, long lddq) {
     __shared__ __attribute__((aligned(16))) bf16_t gs[C * LD];   // g       [i][m]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
@@ -372,10 +390,14 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
             x[0] = a.x * dphi(x[0]); x[1] = a.y * dphi(x[1]); x[2] = a.z * dphi(x[2]);   \
             x[3] = a.w * dphi(x[3]); x[4] = b.x * dphi(x[4]); x[5] = b.y * dphi(x[5]);   \
             x[6] = b.z * dphi(x[6]); x[7] = b.w * dphi(x[7]);                            \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) bsum[j] += x[j];               \
             *reinterpret_cast<uint4*>(dqb + grow * lddq + scol) = pack8(x);              \
         }                                                                                \
     }
 
+    float bsum[8];   // column sums of dQ over this stream (bias gradient of the query projection)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
     CLA_LOAD(0);
     f32x16 T0 = zero16(), T1 = zero16();  // ST_t[m][e] = S[32wj+e][32t+m]: rows m on regs, cols e on lanes
     f32x16 Ta = zero16();                 // ones row: Ta[0][e] = ksum[32wj + e]
@@ -440,6 +462,7 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     CLA_STORE(nch - 1);
 #undef CLA_LOAD
 #undef CLA_STORE
+    if (csum) colsum_store(bsum, os, csum + ((long)n * H + h) * D, tid, lane, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -452,8 +475,8 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
 __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
-    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo,
-    long lddk, long lddv) {
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, float* __restrict__ csum_k, float* __restrict__ csum_v, int H,
+    int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk, long lddv) {
     __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // phi(q)  [i][e]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
@@ -505,11 +528,18 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
             unpack8(*reinterpret_cast<const uint4*>(ok_ + row * LD + scol), x);          \
             unpack8(*reinterpret_cast<const uint4*>(ks + row * LD + scol), f);           \
             _Pragma("unroll") for (int j = 0; j < 8; ++j) x[j] *= fminf(f[j], 1.0f);     \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) bsk[j] += x[j];                \
             *reinterpret_cast<uint4*>(dkb + grow * lddk + scol) = pack8(x);              \
-            *reinterpret_cast<uint4*>(dvb + grow * lddv + scol) =                        \
-                *reinterpret_cast<const uint4*>(ov + row * LD + scol);                   \
+            const uint4 vv = *reinterpret_cast<const uint4*>(ov + row * LD + scol);      \
+            unpack8(vv, f);                                                              \
+            _Pragma("unroll") for (int j = 0; j < 8; ++j) bsv[j] += f[j];                \
+            *reinterpret_cast<uint4*>(dvb + grow * lddv + scol) = vv;                    \
         }                                                                                \
     }
+
+    float bsk[8], bsv[8];   // column sums of dK, dV over this stream (bias gradients of the key / value projections)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) bsk[j] = bsv[j] = 0.f;
 
     CLA_LOAD(nch - 1);
     f32x16 RT0 = zero16(), RT1 = zero16();  // RT_t[m][e] = R[32wj+e][32t+m]: rows m on regs, cols e on lanes
@@ -605,6 +635,11 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     CLA_STORE(0);
 #undef CLA_LOAD
 #undef CLA_STORE
+    if (csum_k) {
+        float* scratch = reinterpret_cast<float*>(wt);   // score tiles are dead after the loop
+        colsum_store(bsk, scratch, csum_k + ((long)n * H + h) * D, tid, lane, w);
+        colsum_store(bsv, scratch, csum_v + ((long)n * H + h) * D, tid, lane, w);
+    }
 }
 
 }  // namespace b16
@@ -617,20 +652,20 @@ int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, 
 }
 
 int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                           const void* dout, void* dq, int N, int H, int L, long ldq, long ldk, long ldv, long ldo,
-                           long lddo, long lddq, hipStream_t st) {
+                           const void* dout, void* dq, float* csum, int N, int H, int L, long ldq, long ldk, long ldv,
+                           long ldo, long lddo, long lddq, hipStream_t st) {
     hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dq, H, L, ldq, ldk,
-                       ldv, ldo, lddo, lddq);
+                       (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dq, csum, H, L, ldq,
+                       ldk, ldv, ldo, lddo, lddq);
     return (int)hipGetLastError();
 }
 
 int launch_cla_bwd_dkdv_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                             const void* dout, void* dk, void* dv, int N, int H, int L, long ldq, long ldk, long ldv,
-                             long ldo, long lddo, long lddk, long lddv, hipStream_t st) {
+                             const void* dout, void* dk, void* dv, float* csum_k, float* csum_v, int N, int H, int L,
+                             long ldq, long ldk, long ldv, long ldo, long lddo, long lddk, long lddv, hipStream_t st) {
     hipLaunchKernelGGL(b16::cla_bwd_dkdv_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dk,
-                       (bf16_t*)dv, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv);
+                       (bf16_t*)dv, csum_k, csum_v, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv);
     return (int)hipGetLastError();
 }
 

@@ -128,7 +128,7 @@ extern "C" {
 
 int cwlt_embed_splits(int64_t rows) {
     int64_t b = (rows + 255) / 256;
-    if (b > 128) b = 128;
+    if (b > 512) b = 512;
     if (b < 1) b = 1;
     return (int)b;
 }

@@ -21,6 +21,10 @@ struct HeadArgs {
     int n_attr;
 };
 
+// exp for the softmax: libm-accurate for f32 logits (parity path), hardware v_exp for bf16 logits
+template <typename T>
+__device__ __forceinline__ float sm_exp(float x) { return sizeof(T) == 2 ? __expf(x) : expf(x); }
+
 // softmax pieces of one attribute segment held 4-per-lane
 struct Seg {
     float x[4];
@@ -31,18 +35,24 @@ template <typename T>
 __device__ __forceinline__ Seg load_seg(const T* row, int off, int n, int lane) {
     Seg s;
     float m = -INFINITY;
+    const int ns = (n + 63) >> 6;            // 64-wide slots in use (wave-uniform): most attributes need one
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int c = lane + 64 * j;
-        s.x[j] = c < n ? load1(row + off + c) : -INFINITY;
-        m = fmaxf(m, s.x[j]);
+        s.x[j] = -INFINITY;
+        if (j < ns) {
+            const int c = lane + 64 * j;
+            s.x[j] = c < n ? load1(row + off + c) : -INFINITY;
+            m = fmaxf(m, s.x[j]);
+        }
     }
     s.mx = wave_max(m);
     float e = 0.f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int c = lane + 64 * j;
-        if (c < n) e += expf(s.x[j] - s.mx);
+        if (j < ns) {
+            const int c = lane + 64 * j;
+            if (c < n) e += sm_exp<T>(s.x[j] - s.mx);
+        }
     }
     s.sum = wave_sum(e);
     return s;
@@ -84,8 +94,8 @@ __global__ __launch_bounds__(256) void heads_fwd_kernel(const T* __restrict__ lo
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const int c = lane + 64 * j;
-                    if (c < n) {
-                        const float p = expf(s.x[j] - s.mx) / s.sum;
+                    if (64 * j < n && c < n) {
+                        const float p = sm_exp<T>(s.x[j] - s.mx) / s.sum;
                         if (probs) probs[r * ldp + off + c] = p;
                         if (p > best) { best = p; bi = c; }
                     }
@@ -141,8 +151,8 @@ __global__ __launch_bounds__(256) void heads_ce_bwd_kernel(const T* __restrict__
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = lane + 64 * j;
-                if (c < n) {
-                    const float p = expf(s.x[j] - s.mx) * inv;
+                if (64 * j < n && c < n) {
+                    const float p = sm_exp<T>(s.x[j] - s.mx) * inv;
                     store1(drow + off + c, (p - (c == (int)t ? 1.f : 0.f)) * w);
                 }
             }

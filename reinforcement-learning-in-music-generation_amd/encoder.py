@@ -87,11 +87,11 @@ class _EncoderLayerFn(torch.autograd.Function):
         da = torch.mm(do, wo_a)                                            # (R, D)
         dwo = wgrad(do, a.view(R, D))
         qkv5 = qkv.view(N, L, 3, H, D // H)
-        dqkv = ops.cla_bwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2], a, zinv, da.view(N, L, H, D // H))
+        dqkv, dbqkv = ops.cla_bwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2], a, zinv, da.view(N, L, H, D // H),
+                                  want_colsum=True)
         dqkv2 = dqkv.view(R, 3 * D)
         dx = torch.addmm(ds1, dqkv2, wqkv)                                 # residual + projection gradient
         dwqkv = wgrad(dqkv2, x2)                                           # (3D, D)
-        dbqkv = ops.colsum(dqkv2)
         layer = ctx.layer
         if layer is not None and ops.direct_grads():
             # single process: write the 16 parameter gradients straight into .grad (flat f32 buckets),

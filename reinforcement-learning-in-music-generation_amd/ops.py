@@ -130,8 +130,9 @@ def cla_fwd(q, k, v, eps=CLA_EPS):
     return q, k, v, out, zinv
 
 
-def cla_bwd(q, k, v, out, zinv, dout):
-    """-> dqkv (N, L, 3, H, 64): dq | dk | dv side by side (= gradient of a fused QKV projection)."""
+def cla_bwd(q, k, v, out, zinv, dout, want_colsum=False):
+    """-> dqkv (N, L, 3, H, 64): dq | dk | dv side by side (= gradient of a fused QKV projection)
+    [, dbias (3*H*64) f32 = its column sums, fused into the kernels on the bf16 path]."""
     lib = _lib.load()
     N, L, H, D = q.shape
     dout, lddo = _as_rows(dout)
@@ -142,11 +143,20 @@ def cla_bwd(q, k, v, out, zinv, dout):
     ld = 3 * H * D
     common = (_lib.dev(q), _lib.dev(k), _lib.dev(v), _lib.dev(out), _lib.dev(zinv), _lib.dev(dout, "dout"))
     code, st = _lib.dtype_code(q.dtype), _lib.stream_ptr()
-    _call("cwlt_causal_linear_bwd_dkdv", *common, _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]), N, H, L, D,
+    fused = (want_colsum and q.dtype == torch.bfloat16 and all(x % 8 == 0 for x in (ldq, ldk, ldv, lddo)))
+    cs = torch.empty((3, N, H * D), dtype=torch.float32, device=q.device) if fused else None
+    _call("cwlt_causal_linear_bwd_dkdv", *common, _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]),
+          _lib.dev(cs[1]) if fused else None, _lib.dev(cs[2]) if fused else None, N, H, L, D,
           ldq, ldk, ldv, H * D, lddo, ld, ld, code, st)
-    _call("cwlt_causal_linear_bwd_dq", *common, _lib.dev(dqkv[:, :, 0]), N, H, L, D,
-          ldq, ldk, ldv, H * D, lddo, ld, code, st)
-    return dqkv
+    _call("cwlt_causal_linear_bwd_dq", *common, _lib.dev(dqkv[:, :, 0]), _lib.dev(cs[0]) if fused else None,
+          N, H, L, D, ldq, ldk, ldv, H * D, lddo, ld, code, st)
+    if not want_colsum:
+        return dqkv
+    if fused:
+        dbias = cs.sum(1).reshape(3 * H * D) if N > 1 else cs.reshape(3 * H * D)
+    else:
+        dbias = colsum(dqkv.view(N * L, 3 * H * D))
+    return dqkv, dbias
 
 
 class CausalLinearAttentionFn(torch.autograd.Function):
