@@ -204,6 +204,15 @@ int cwlt_wgrad_splits(int64_t M, int N1, int N2);
 int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64_t M, int N1, int N2,
                     int64_t lda, int64_t ldb, int accumulate, void* stream);
 
+/* ---- recurrent (generation) form of the causal linear attention ------------------------------------
+ * One token: Zi += phi(k); Si += phi(k) (x) v; out = (phi(q) . Si) / (phi(q) . Zi + eps), state updated in
+ * place.  Replaces fast_transformers RecurrentLinearAttention.forward as built by RecurrentEncoderBuilder at
+ * dqn_policy/model.py:141-150 and driven by dqn_policy/testing-no-type-cp.py:126-179.
+ * q, k, v, out: (N, H*64) rows (row strides ld*); S (N, H, 64, 64) f32; Z (N, H, 64) f32. */
+int cwlt_recurrent_cla_step(const void* q, const void* k, const void* v, float* S, float* Z, void* out,
+                            int N, int H, int head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                            float eps, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,7 @@ _SIGNATURES = {
     "cwlt_band_attn_fwd": [_ptr] * 5 + [_c_int] * 5 + [_c_i64] * 4 + [_c_f32, _c_f32, _c_u64, _c_int, _ptr],
     "cwlt_wgrad_splits": [_c_i64, _c_int, _c_int],
     "cwlt_wgrad_bf16": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_recurrent_cla_step": [_ptr] * 6 + [_c_int] * 3 + [_c_i64] * 4 + [_c_f32, _c_int, _ptr],
     "cwlt_heads_blocks": [_c_i64],
     "cwlt_heads_fwd": [_ptr, _ptr, _c_int] + [_ptr] * 7 + [_c_i64, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_heads_ce_bwd": [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],

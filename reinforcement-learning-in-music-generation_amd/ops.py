@@ -473,5 +473,21 @@ def band_attention(q, k, v, mask, window, p=0.0, seed=0):
     return out
 
 
+def recurrent_cla_step(qkv, S, Z, H, eps=CLA_EPS):
+    """qkv (N, 3*H*64) fused projections of ONE token per sequence; S (N, H, 64, 64), Z (N, H, 64) f32 states,
+    updated in place.  -> (N, H*64)."""
+    N, W = qkv.shape
+    D = W // 3
+    qkv = qkv.contiguous()
+    out = torch.empty((N, D), dtype=qkv.dtype, device=qkv.device)
+    esz = qkv.element_size()
+    base = qkv.data_ptr()
+    import ctypes
+    _call("cwlt_recurrent_cla_step", ctypes.c_void_p(base), ctypes.c_void_p(base + D * esz),
+          ctypes.c_void_p(base + 2 * D * esz), _lib.dev(S, "S"), _lib.dev(Z, "Z"), _lib.dev(out), N, H, D // H,
+          W, W, W, D, float(eps), _lib.dtype_code(qkv.dtype), _lib.stream_ptr())
+    return out
+
+
 def sqrt_width(w):
     return math.sqrt(w)

@@ -6,9 +6,10 @@ Surface of fast_transformers' RecurrentEncoderBuilder product as the reference u
 with per-layer state [S (N, H, 64, 64), Zs (N, H, 64)].  Parameter names equal the training
 encoder's, so checkpoints interchange.
 
-Scope note: generation is OUTSIDE the training hot path this round.  The
-step below is latency-bound GEMV-sized work expressed with torch GPU ops (no CPU path); a persistent
-single-kernel decode step is listed as the next widening step.
+The per-token attention step (state update + normalised read-out, elu+1 inside) is one libcwlt kernel
+(csrc/recurrent.hip); LayerNorm / FFN activation reuse the training kernels; the projections are
+GEMV-sized hipBLASLt calls.  Generation is outside the training hot path: a persistent
+single-launch decode step across all 12 layers is the natural next step.
 """
 import torch
 import torch.nn as nn
@@ -30,24 +31,29 @@ class RecurrentTransformerEncoderLayer(nn.Module):
     def forward(self, x, state=None):
         at = self.attention
         N, H = x.shape[0], at.n_heads
-        q = F.elu(at.query_projection(x).view(N, H, -1)) + 1
-        k = F.elu(at.key_projection(x).view(N, H, -1)) + 1
-        v = at.value_projection(x).view(N, H, -1)
-        if state is None:
-            S = x.new_zeros((N, H, q.shape[-1], v.shape[-1]))
-            Zs = x.new_zeros((N, H, q.shape[-1]))
-        else:
-            S, Zs = state
-            if len(S) != N:
-                raise ValueError("The batch size changed during iteration")
-        Zs = Zs + k
-        S = S + torch.einsum("nhd,nhm->nhdm", k, v)
-        Z = 1.0 / (torch.einsum("nhd,nhd->nh", q, Zs) + ops.CLA_EPS)
-        a = torch.einsum("nhd,nhdm,nh->nhm", q, S, Z).reshape(N, -1)
-        x = self.norm1(x + self.dropout(at.out_projection(a)))
-        y = self.dropout(F.gelu(self.linear1(x)))
-        y = self.dropout(self.linear2(y))
-        return self.norm2(x + y), [S, Zs]
+        D = x.shape[1]
+        with torch.no_grad():
+            wqkv = torch.cat([at.query_projection.weight, at.key_projection.weight, at.value_projection.weight], 0)
+            bqkv = torch.cat([at.query_projection.bias, at.key_projection.bias, at.value_projection.bias], 0)
+            qkv = torch.addmm(bqkv.to(x.dtype), x, wqkv.to(x.dtype).t())            # (N, 3D)
+            if state is None:
+                S = torch.zeros((N, H, D // H, D // H), dtype=torch.float32, device=x.device)
+                Zs = torch.zeros((N, H, D // H), dtype=torch.float32, device=x.device)
+            else:
+                S, Zs = state
+                if len(S) != N:
+                    raise ValueError("The batch size changed during iteration")
+            a = ops.recurrent_cla_step(qkv, S, Zs, H)                                # state updated in place
+            p = self.dropout.p if self.training else 0.0
+            o = at.out_projection(a)
+            _, x1, _, _ = ops.ln_fwd(x.contiguous(), o, ops._f32(self.norm1.weight), ops._f32(self.norm1.bias),
+                                     self.norm1.eps, p, ops.next_seed() if p > 0 else 0, save_s=False)
+            h = torch.mm(x1, self.linear1.weight.to(x.dtype).t())
+            g = ops.gelu_fwd(h, ops._f32(self.linear1.bias), p, ops.next_seed() if p > 0 else 0)
+            y = self.linear2(g)
+            _, x2, _, _ = ops.ln_fwd(x1, y, ops._f32(self.norm2.weight), ops._f32(self.norm2.bias), self.norm2.eps, p,
+                                     ops.next_seed() if p > 0 else 0, save_s=False)
+        return x2, [S, Zs]
 
 
 class RecurrentTransformerEncoder(nn.Module):
@@ -67,5 +73,6 @@ class RecurrentTransformerEncoder(nn.Module):
         for i, layer in enumerate(self.layers):
             x, state[i] = layer(x, state[i])
         if self.norm is not None:
-            x = self.norm(x)
+            with torch.no_grad():
+                x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x, state
