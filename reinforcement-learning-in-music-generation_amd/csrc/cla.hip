@@ -501,8 +501,9 @@ int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* ou
                            int L, int head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float eps,
                            int dtype, void* stream) {
     using namespace cwlt;
-    if (!q || !k || !v || !out || !zinv) return CWLT_ERR_ARG;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
+    if (N == 0 || L == 0) return CWLT_OK;                     // empty batch / sequence: nothing to do
+    if (!q || !k || !v || !out || !zinv) return CWLT_ERR_ARG;
     if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H)) return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;
     hipStream_t st = (hipStream_t)stream;
@@ -521,8 +522,9 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddk,
                                 int64_t lddv, int dtype, void* stream) {
     using namespace cwlt;
-    if (!q || !k || !v || !out || !zinv || !dout || !dk || !dv) return CWLT_ERR_ARG;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
+    if (N == 0 || L == 0) return CWLT_OK;
+    if (!q || !k || !v || !out || !zinv || !dout || !dk || !dv) return CWLT_ERR_ARG;
     if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H) || bad_ld(lddo, H) ||
         bad_ld(lddk, H) || bad_ld(lddv, H))
         return CWLT_ERR_ARG;
@@ -549,8 +551,9 @@ int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const
                               int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int dtype,
                               void* stream) {
     using namespace cwlt;
-    if (!q || !k || !v || !out || !zinv || !dout || !dq) return CWLT_ERR_ARG;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
+    if (N == 0 || L == 0) return CWLT_OK;
+    if (!q || !k || !v || !out || !zinv || !dout || !dq) return CWLT_ERR_ARG;
     if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H) || bad_ld(lddo, H) || bad_ld(lddq, H))
         return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;

@@ -142,8 +142,9 @@ int cwlt_cw_embed_fwd(const int64_t* tokens, const void* const* tables, const in
     EmbedArgs a;
     int e = fill_args(a, tables, widths, nrows, n_attr);
     if (e) return e;
-    if (!tokens || !out || rows < 0 || ldo < a.dcat || (ldo & 3)) return CWLT_ERR_ARG;
+    if (rows < 0 || ldo < a.dcat || (ldo & 3)) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
+    if (!tokens || !out) return CWLT_ERR_ARG;
     const int rpb = 16;
     const dim3 grid((unsigned)((rows + rpb - 1) / rpb)), block(256);
     hipStream_t st = (hipStream_t)stream;
@@ -168,9 +169,10 @@ int cwlt_cw_embed_bwd(const int64_t* tokens, const int* widths, const int* nrows
     for (int f = 0; f < CWLT_MAX_ATTR; ++f) dummy[f] = (const void*)dtables;
     int e = fill_args(a, dummy, widths, nrows, n_attr);
     if (e) return e;
-    if (!tokens || !dout || !part || !dtables || rows < 0 || ldd < a.dcat) return CWLT_ERR_ARG;
+    if (!dtables || rows < 0 || ldd < a.dcat) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return (int)hipMemsetAsync(dtables, 0, sizeof(float) * a.total, st);
+    if (!tokens || !dout || !part) return CWLT_ERR_ARG;
     int maxr = 0;
     for (int f = 0; f < n_attr; ++f) maxr = nrows[f] > maxr ? nrows[f] : maxr;
     const size_t lds = (size_t)maxr * 64 * sizeof(float);

@@ -18,6 +18,8 @@ LN_EPS = 1e-5   # nn.LayerNorm default, used by fast_transformers' encoder layer
 def _row_stride(t):
     """(N, L, H, D) view whose last two dims are dense and whose batch stride is L*row_stride."""
     N, L, H, D = t.shape
+    if t.numel() == 0:
+        return H * D                 # empty batch / sequence: strides are irrelevant
     if t.stride(3) != 1 or t.stride(2) != D:
         return None
     ld = t.stride(1)

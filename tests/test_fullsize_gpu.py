@@ -1,0 +1,120 @@
+"""GPU: parity at the benchmark's FULL sizes (B=64, T=1024, repo dims) through size-independent properties --
+the CPU oracle cannot run these sizes in seconds -- plus empty / ragged edge cases of the C-ABI."""
+import pytest
+import torch
+
+import rlmg_amd  # noqa: F401
+from rlmg_amd import ops
+
+pytestmark = pytest.mark.gpu
+B, T, H = 64, 1024, 8
+
+
+def _qkv(dtype, seed, cuda):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.randn(B, T, 3, H, 64, generator=g).to(dtype).to(cuda)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 3e-2)])
+def test_scan_is_linear_in_values_at_full_size(cuda, dtype, tol):
+    """out(q, k, a v1 + b v2) = a out(q, k, v1) + b out(q, k, v2): the normaliser depends on q, k only."""
+    x = _qkv(dtype, 1, cuda)
+    v2 = torch.randn_like(x[:, :, 2])
+    q, k, v1 = x[:, :, 0], x[:, :, 1], x[:, :, 2]
+    lhs = ops.causal_linear_attention(q, k, (0.5 * v1.float() - 2.0 * v2.float()).to(dtype))
+    rhs = 0.5 * ops.causal_linear_attention(q, k, v1).float() - 2.0 * ops.causal_linear_attention(q, k, v2).float()
+    assert (lhs.float() - rhs).abs().max().item() < tol * max(1.0, rhs.abs().max().item())
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_scan_is_causal_and_batch_independent_at_full_size(cuda, dtype):
+    x = _qkv(dtype, 2, cuda)
+    a = ops.causal_linear_attention(x[:, :, 0], x[:, :, 1], x[:, :, 2])
+    y = x.clone()
+    y[:, 700:, 1:] = torch.randn_like(y[:, 700:, 1:])          # change k, v from token 700 on
+    b = ops.causal_linear_attention(y[:, :, 0], y[:, :, 1], y[:, :, 2])
+    assert torch.equal(a[:, :700], b[:, :700]) and not torch.equal(a[:, 700:], b[:, 700:])
+    c = ops.causal_linear_attention(x[5:9, :, 0], x[5:9, :, 1], x[5:9, :, 2])   # sequences are independent streams
+    assert torch.equal(c, a[5:9])
+
+
+def test_scan_constant_values_give_constant_output(cuda):
+    """With v_j = c for all j the normalised output is c (up to eps): a check of the normaliser at T = 1024."""
+    x = _qkv(torch.float32, 3, cuda)
+    c = torch.randn(1, 1, H, 64, device=cuda)
+    out = ops.causal_linear_attention(x[:, :, 0], x[:, :, 1], c.expand(B, T, H, 64).contiguous())
+    assert (out - c).abs().max().item() < 1e-4
+
+
+def test_recurrent_equals_chunked_scan_at_t1024(cuda):
+    N = 4
+    x = _qkv(torch.float32, 4, cuda)[:N]
+    par = ops.causal_linear_attention(x[:, :, 0], x[:, :, 1], x[:, :, 2])
+    S = torch.zeros(N, H, 64, 64, device=cuda)
+    Z = torch.zeros(N, H, 64, device=cuda)
+    worst = 0.0
+    for t in range(T):
+        got = ops.recurrent_cla_step(x[:, t].reshape(N, 3 * H * 64), S, Z, H)
+        if t % 97 == 0 or t == T - 1:
+            worst = max(worst, (got.view(N, H, 64) - par[:, t]).abs().max().item())
+    assert worst < 1e-4
+
+
+def test_scan_backward_matches_finite_difference_direction_at_full_size(cuda):
+    """<grad, d> vs (f(x + h d) - f(x - h d)) / 2h for a random direction d, f = <out, w> (fp32 path)."""
+    x = _qkv(torch.float32, 5, cuda)[:8].clone().requires_grad_(True)
+    w = torch.randn(8, T, H, 64, device=cuda) / (T * H * 64) ** 0.5
+    d = torch.randn_like(x)
+    f = lambda z: (ops.causal_linear_attention(z[:, :, 0], z[:, :, 1], z[:, :, 2]).double() * w.double()).sum()
+    f(x).backward()
+    lin = (x.grad.double() * d.double()).sum().item()
+    hstep = 1e-2
+    with torch.no_grad():
+        fd = ((f(x + hstep * d) - f(x - hstep * d)) / (2 * hstep)).item()
+    assert abs(lin - fd) <= 2e-3 * max(1.0, abs(fd)), (lin, fd)
+
+
+def test_wgrad_and_fused_bias_sums_at_full_size(cuda):
+    R = B * T
+    a = torch.randn(R, 1536, device=cuda).bfloat16()
+    x = torch.randn(R, 512, device=cuda).bfloat16()
+    ref = torch.mm(a.float().t(), x.float())
+    got = ops.wgrad(a, x)
+    assert (got - ref).abs().max().item() <= 2e-3 * ref.abs().max().item()     # torch.mm f32 vs split order
+    q = _qkv(torch.bfloat16, 6, cuda)
+    _, _, _, out, zinv = ops.cla_fwd(q[:, :, 0], q[:, :, 1], q[:, :, 2])
+    dout = torch.randn_like(out)
+    dqkv, dbias = ops.cla_bwd(q[:, :, 0], q[:, :, 1], q[:, :, 2], out, zinv, dout, want_colsum=True)
+    ref_b = dqkv.float().view(R, -1).sum(0)
+    assert (dbias - ref_b).abs().max().item() <= 2e-2 * max(1.0, ref_b.abs().max().item())
+
+
+def test_dropout_masks_are_a_function_of_seed_and_index_only(cuda):
+    """Same (seed, index) -> same mask whatever the dtype / vector width / kernel; keep rate = 1 - p."""
+    R, F = 4096, 2048
+    h = torch.ones(R, F, device=cuda) * 3.0
+    z = torch.zeros(F, device=cuda)
+    g32 = ops.gelu_fwd(h, z, p=0.1, seed=77) != 0
+    g16 = ops.gelu_fwd(h.bfloat16(), z, p=0.1, seed=77) != 0
+    pe = ops.posenc_dropout(h, None, 1, p=0.1, seed=77) != 0
+    assert torch.equal(g32, g16) and torch.equal(g32, pe)
+    assert abs(g32.float().mean().item() - 0.9) < 2e-3
+
+
+def test_empty_and_ragged_inputs(cuda):
+    e = torch.empty(0, 16, 8, 64, device=cuda)
+    assert ops.causal_linear_attention(e, e, e).shape == (0, 16, 8, 64)
+    z = torch.empty(2, 0, 8, 64, device=cuda)
+    assert ops.causal_linear_attention(z, z, z).shape == (2, 0, 8, 64)
+    for L in (1, 31, 32, 33, 63, 64, 65, 127):                      # chunk boundaries of both scan paths
+        for dt in (torch.float32, torch.bfloat16):
+            x = torch.randn(2, L, 3, 2, 64, device=cuda).to(dt).requires_grad_(True)
+            out = ops.causal_linear_attention(x[:, :, 0], x[:, :, 1], x[:, :, 2])
+            out.float().sum().backward()
+            assert torch.isfinite(out.float()).all() and torch.isfinite(x.grad.float()).all()
+    tok = torch.zeros(0, 6, dtype=torch.int64, device=cuda)
+    tabs = [torch.randn(5, 64, device=cuda) for _ in range(6)]
+    assert ops.cw_embed(tok, tabs).shape == (0, 384)
+    with pytest.raises(RuntimeError):                                # head_dim != 64 is refused, not mis-computed
+        bad = torch.randn(1, 4, 2, 32, device=cuda)
+        ops.causal_linear_attention(bad, bad, bad)
