@@ -150,15 +150,28 @@ int cwlt_heads_ce_bwd(const void* logits, const int* n_class, int n_attr, const 
                       const float* mask, const float* coef, void* dlogits, int64_t rows, int64_t ld,
                       int dtype, void* stream);
 
-/* ---- sliding-window attention of the AIRL discriminator (forward) --------------------------------
+/* ---- sliding-window attention of the AIRL discriminator --------------------------------
  * Replaces HF LongformerSelfAttention.forward (banded scores -> fp32 softmax -> probs @ value) as
  * reached from dqn_policy/AIRL_model.py:78-90,117 (attention_window 50) and ppo_policy/model.py:440-451,470
  * (attention_window 512).  q, k, v, out: (B, L, H, 64), row strides ld*; mask (B, L) f32, nonzero =
  * attend (NULL = all); window = one-sided width (attention_window / 2); scale = 1/sqrt(64) applied to q;
  * masked queries produce zero rows; p = dropout on the probabilities. */
-int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out,
+int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, float* lse,
                        int B, int H, int L, int head_dim, int window,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+                       float scale, float p, uint64_t seed, int dtype, void* stream);
+
+/* Backward of cwlt_band_attn_fwd -- what torch autograd derives through HF LongformerSelfAttention when the
+ * reference trains the discriminator (dqn_policy/AIRL.py:135-170, global_loss.backward()).  lse (B, H, L) f32 =
+ * the forward's optional log-sum-exp output (+inf on zeroed query rows; pass NULL to the forward when no
+ * backward follows); out = the forward's output; dout its gradient (row stride lddo).  dq, dk, dv: gradients
+ * w.r.t. the raw q, k, v, same (B, L, H, 64) layout with row strides lddq / lddk / lddv.  The dropout mask is
+ * regenerated from (seed, b, h, i, j). */
+int cwlt_band_attn_bwd(const void* q, const void* k, const void* v, const float* mask, const void* out,
+                       const float* lse, const void* dout, void* dq, void* dk, void* dv,
+                       int B, int H, int L, int head_dim, int window,
+                       int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                       int64_t lddq, int64_t lddk, int64_t lddv,
                        float scale, float p, uint64_t seed, int dtype, void* stream);
 
 /* Gradient of sum_{r,f} w[r][f] * log softmax_f(logits_r)[target[r][f]] w.r.t. the logits, given as the kernel

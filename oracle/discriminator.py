@@ -4,7 +4,9 @@ Follows /root/reference/dqn_policy/AIRL_model.py:101-122 (`LongFormer.forward`: 
 cat -> proj -> Longformer -> mean over seq -> score_classifier) and ppo_policy/model.py:459-495
 (`LongFormer.token_forward`: ... -> 6 heads -> eval_f -> mean over seq -> sigmoid -> mean of 6), operating on
 the modules' state dicts.  Pinned by tests/golden/{airl_small,ppo_reward_small}.npz, recorded from the
-reference's own classes (tests/golden/make_golden.py).
+reference's own classes (tests/golden/make_golden.py).  `airl_token_ce` / `airl_disc_loss` restate
+AIRL_model.py:131-170 and the loss of AIRL.py:150-170; every function is plain differentiable torch, and the
+gradients are pinned by tests/golden/airl_grads_small.npz (the reference's own backward).
 """
 import math
 
@@ -45,3 +47,24 @@ def ppo_reward_forward(sd, data, masks, n_layer, n_head, attention_window):
         hid = F.linear(y, sd["eval_%s.weight" % a], sd["eval_%s.bias" % a]).mean(dim=1)
         total = total + torch.sigmoid(hid)
     return total / len(ATTRS)
+
+
+def airl_token_ce(sd, data, target, masks, n_layer, n_head, attention_window):
+    """dqn_policy/AIRL_model.py:131-170 `token_forward`: mean over the 6 heads of compute_CEloss, which is
+    (mean CE * mask).sum() / mask.sum() == the plain mean CE over all positions (:125-129)."""
+    x = _embed_proj(sd, data)
+    h = olf.longformer_forward(sd, x, masks, n_layer, n_head, attention_window // 2, prefix="longformer.")
+    total = 0
+    for i, a in enumerate(ATTRS):
+        y = F.linear(h, sd["proj_%s.weight" % a], sd["proj_%s.bias" % a])
+        total = total + F.cross_entropy(y.reshape(-1, y.shape[-1]), target[..., i].reshape(-1))
+    return total / len(ATTRS)
+
+
+def airl_disc_loss(sd, x_exp, x_agent, masks, n_layer, n_head, attention_window):
+    """One batch of dqn_policy/AIRL.py:150-170 in eval mode: (BCE(expert, 1), BCE(agent, 0), token CE)."""
+    s_exp = airl_forward(sd, x_exp, masks, n_layer, n_head, attention_window)
+    s_ag = airl_forward(sd, x_agent, masks, n_layer, n_head, attention_window)
+    ce = airl_token_ce(sd, x_agent, x_exp, masks, n_layer, n_head, attention_window)
+    return (F.binary_cross_entropy(s_exp, torch.ones_like(s_exp)),
+            F.binary_cross_entropy(s_ag, torch.zeros_like(s_ag)), ce)

@@ -26,8 +26,8 @@ constexpr int BLD = 65;  // LDS row stride
 template <typename T>
 __global__ __launch_bounds__(256) void band_attn_fwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                             const T* __restrict__ v, const float* __restrict__ mask,
-                                                            T* __restrict__ out, int H, int L, int w, long ldq,
-                                                            long ldk, long ldv, long ldo, float scale,
+                                                            T* __restrict__ out, float* __restrict__ lse, int H, int L,
+                                                            int w, long ldq, long ldk, long ldv, long ldo, float scale,
                                                             uint32_t thresh, float keep_scale, uint64_t seed) {
     __shared__ float qs[BT * BLD];
     __shared__ float ks[BT * BLD];
@@ -167,6 +167,218 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(const T* __restrict_
         const bool qok = !mb || mb[i] != 0.f;
         const float inv = (qok && l_run[a] > 0.f) ? 1.0f / l_run[a] : 0.f;
         store4(ob + (long)i * ldo + 4 * tj, make_float4(o[a][0] * inv, o[a][1] * inv, o[a][2] * inv, o[a][3] * inv));
+        // log-sum-exp of the row (for the backward); +inf marks rows whose output is forced to zero
+        if (lse && tj == 0) lse[((long)b * H + h) * L + i] = (qok && l_run[a] > 0.f) ? m_run[a] + logf(l_run[a]) : INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward.  P_ij = exp(s_ij - lse_i) inside the band (0 for masked keys / masked queries), Pd = dropout(P),
+//   O = Pd V;  dV_j = sum_i Pd_ij dO_i;  dP_ij = keep_ij * (dO_i . V_j);  delta_i = dO_i . O_i
+//   dS_ij = P_ij (dP_ij - delta_i);  dQ_i = scale * sum_j dS_ij K_j;  dK_j = scale * sum_i dS_ij Q_i   (q unscaled)
+// Two kernels, both recompute the 64x64 score tile from LDS-staged tiles with f32 FMAs:
+//   dq kernel: one workgroup per 64 queries, loops key tiles; dkdv kernel: one workgroup per 64 keys, loops query tiles.
+// ------------------------------------------------------------------------------------------------
+template <typename T, bool FOR_KV>
+__global__ __launch_bounds__(256) void band_attn_bwd_kernel(const T* __restrict__ q, const T* __restrict__ k,
+                                                            const T* __restrict__ v, const float* __restrict__ mask,
+                                                            const T* __restrict__ out, const T* __restrict__ dout,
+                                                            const float* __restrict__ lse, T* __restrict__ g1,
+                                                            T* __restrict__ g2, int H, int L, int w, long ldq, long ldk,
+                                                            long ldv, long ldo, long lddo, long ldg1, long ldg2,
+                                                            float scale, uint32_t thresh, float keep_scale,
+                                                            uint64_t seed) {
+    // "own" tile = the 64 rows this workgroup produces gradients for (queries for dq, keys for dk/dv);
+    // "other" tile = the rows it loops over.
+    __shared__ float a_s[BT * BLD];   // own tile, first operand  (dq: q*scale   | dkdv: k)
+    __shared__ float b_s[BT * BLD];   // other tile, first operand (dq: k        | dkdv: q*scale)
+    __shared__ float c_s[BT * BLD];   // dq: v (other)           | dkdv: v (own)
+    __shared__ float d_s[BT * BLD];   // dq: dO (own)            | dkdv: dO (other)
+    __shared__ float p_s[BT * BLD];   // dS (dq) / Pd then dS (dkdv), [own][other]
+    __shared__ float r_lse[BT], r_del[BT], r_ok[BT];   // per QUERY row of the current query tile
+
+    const int tid = threadIdx.x;
+    const int ti = tid >> 4, tj = tid & 15;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int own0 = blockIdx.x * BT;
+    const T* qb = q + ((long)b * L) * ldq + h * BD;
+    const T* kb = k + ((long)b * L) * ldk + h * BD;
+    const T* vb = v + ((long)b * L) * ldv + h * BD;
+    const T* ob = out + ((long)b * L) * ldo + h * BD;
+    const T* gb = dout + ((long)b * L) * lddo + h * BD;
+    const float* mb = mask ? mask + (long)b * L : nullptr;
+    const float* lb = lse + ((long)b * H + h) * L;
+
+    auto stage = [&](float* dst, const T* src, long ld, int r0, float mul) {
+        for (int e = tid; e < BT * (BD / 4); e += 256) {
+            const int r = e >> 4, c4 = (e & 15) * 4;
+            float4 x = make_float4(0, 0, 0, 0);
+            if (r0 + r < L) x = load4(src + (long)(r0 + r) * ld + c4);
+            float* p = dst + r * BLD + c4;
+            p[0] = x.x * mul; p[1] = x.y * mul; p[2] = x.z * mul; p[3] = x.w * mul;
+        }
+    };
+    // per-query-row statistics of query tile starting at q0: lse, delta = dO . O, validity
+    auto row_stats = [&](int q0) {
+        for (int r = tid >> 2; r < BT; r += 64) {
+            const int i = q0 + r;
+            float d = 0.f;
+            if (i < L) {
+                for (int c = (tid & 3) * 16; c < (tid & 3) * 16 + 16; c += 4) {
+                    const float4 x = load4(gb + (long)i * lddo + c), y = load4(ob + (long)i * ldo + c);
+                    d += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+                }
+            }
+            d += __shfl_xor(d, 1, 64);
+            d += __shfl_xor(d, 2, 64);
+            if ((tid & 3) == 0) {
+                const float ls = i < L ? lb[i] : INFINITY;
+                r_lse[r] = ls;
+                r_del[r] = d;
+                r_ok[r] = (i < L && ls != INFINITY) ? 1.f : 0.f;
+            }
+        }
+    };
+
+    float acc1[4][4], acc2[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc1[a][c] = acc2[a][c] = 0.f;
+
+    if (FOR_KV) {
+        stage(a_s, kb, ldk, own0, 1.f);
+        stage(c_s, vb, ldv, own0, 1.f);
+    } else {
+        stage(a_s, qb, ldq, own0, scale);
+        stage(d_s, gb, lddo, own0, 1.f);
+        row_stats(own0);
+    }
+    int t0 = (own0 - w) / BT;
+    if (own0 - w < 0) t0 = 0;
+    int t1 = (own0 + BT - 1 + w) / BT;
+    const int tmax = (L - 1) / BT;
+    if (t1 > tmax) t1 = tmax;
+
+    for (int t = t0; t <= t1; ++t) {
+        const int oth0 = t * BT;
+        __syncthreads();
+        if (FOR_KV) {
+            stage(b_s, qb, ldq, oth0, scale);
+            stage(d_s, gb, lddo, oth0, 1.f);
+            row_stats(oth0);
+        } else {
+            stage(b_s, kb, ldk, oth0, 1.f);
+            stage(c_s, vb, ldv, oth0, 1.f);
+        }
+        __syncthreads();
+        // this thread's 4x4 block of [own][other]: s = a_own . b_other ; dp = (dO . V) taken query-major
+        float sc[4][4], dp[4][4];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) sc[a][c] = dp[a][c] = 0.f;
+#pragma unroll 8
+        for (int d = 0; d < BD; ++d) {
+            float xa[4], xb[4], ya[4], yb[4];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                xa[a] = a_s[(4 * ti + a) * BLD + d];
+                ya[a] = FOR_KV ? c_s[(4 * ti + a) * BLD + d] : d_s[(4 * ti + a) * BLD + d];   // own: v | dO
+            }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                xb[c] = b_s[(4 * tj + c) * BLD + d];
+                yb[c] = FOR_KV ? d_s[(4 * tj + c) * BLD + d] : c_s[(4 * tj + c) * BLD + d];   // other: dO | v
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    sc[a][c] = fmaf(xa[a], xb[c], sc[a][c]);
+                    dp[a][c] = fmaf(ya[a], yb[c], dp[a][c]);
+                }
+        }
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const int ro = 4 * ti + a, rt = 4 * tj + c;            // row in own tile / other tile
+                const int qi = FOR_KV ? oth0 + rt : own0 + ro;         // query index, key index
+                const int kj = FOR_KV ? own0 + ro : oth0 + rt;
+                const int qr = FOR_KV ? rt : ro;                       // query row inside its tile (stats)
+                const int dlt = qi - kj;
+                const bool ok = qi < L && kj < L && dlt <= w && dlt >= -w && r_ok[qr] != 0.f && (!mb || mb[kj] != 0.f);
+                float p = ok ? expf(sc[a][c] - r_lse[qr]) : 0.f;
+                float keep = 1.f;
+                if (thresh && ok) {
+                    const uint64_t idx = (((uint64_t)bh * L + (uint64_t)qi) * L) + (uint64_t)kj;
+                    keep = dropout_keep(seed, idx, thresh) ? keep_scale : 0.f;
+                }
+                const float ds = p * (dp[a][c] * keep - r_del[qr]);
+                if (FOR_KV) {
+                    sc[a][c] = p * keep;    // Pd[own key][query]
+                    dp[a][c] = ds;          // dS[own key][query]
+                } else {
+                    p_s[ro * BLD + rt] = ds;
+                }
+            }
+        if (FOR_KV) {
+            // dV[own] += Pd . dO(other) ; dK[own] += dS . (q*scale)(other) -- two passes through p_s
+#pragma unroll
+            for (int pass = 0; pass < 2; ++pass) {
+                __syncthreads();
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) p_s[(4 * ti + a) * BLD + 4 * tj + c] = pass == 0 ? sc[a][c] : dp[a][c];
+                __syncthreads();
+                const float* src = pass == 0 ? d_s : b_s;
+#pragma unroll 8
+                for (int j = 0; j < BT; ++j) {
+                    float pa[4], vc[4];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) pa[a] = p_s[(4 * ti + a) * BLD + j];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) vc[c] = src[j * BLD + 4 * tj + c];
+#pragma unroll
+                    for (int a = 0; a < 4; ++a)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            if (pass == 0) acc2[a][c] = fmaf(pa[a], vc[c], acc2[a][c]);
+                            else acc1[a][c] = fmaf(pa[a], vc[c], acc1[a][c]);
+                        }
+                }
+            }
+        } else {
+            __syncthreads();
+            // dQ[own] += dS . K(other)
+#pragma unroll 8
+            for (int j = 0; j < BT; ++j) {
+                float pa[4], vc[4];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) pa[a] = p_s[(4 * ti + a) * BLD + j];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) vc[c] = b_s[j * BLD + 4 * tj + c];
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) acc1[a][c] = fmaf(pa[a], vc[c], acc1[a][c]);
+            }
+        }
+    }
+    // dq kernel: g1 = dQ = scale * acc1 (a_s already carried one factor `scale` on q; K unscaled -> multiply once more? no:
+    // s = (q*scale).k, dS is w.r.t. s, so dq = scale * dS K and dk = dS^T (q*scale) -- b_s holds q*scale already)
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+        const int i = own0 + 4 * ti + a;
+        if (i >= L) continue;
+        const float m = FOR_KV ? 1.f : scale;
+        store4(g1 + ((long)b * L + i) * ldg1 + h * BD + 4 * tj,
+               make_float4(acc1[a][0] * m, acc1[a][1] * m, acc1[a][2] * m, acc1[a][3] * m));
+        if (FOR_KV)
+            store4(g2 + ((long)b * L + i) * ldg2 + h * BD + 4 * tj,
+                   make_float4(acc2[a][0], acc2[a][1], acc2[a][2], acc2[a][3]));
     }
 }
 
@@ -176,8 +388,8 @@ extern "C" {
 
 /* mask: (B, L) f32, nonzero = attend (HF attention_mask), may be NULL.  window = ONE-SIDED width w
  * (HF attention_window / 2).  p = dropout on the attention probabilities (0 in eval). */
-int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, int B, int H,
-                       int L, int head_dim, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
+int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, float* lse, int B,
+                       int H, int L, int head_dim, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                        float scale, float p, uint64_t seed, int dtype, void* stream) {
     using namespace cwlt;
     if (!q || !k || !v || !out || B < 0 || H <= 0 || L < 0 || head_dim != BD || window < 0) return CWLT_ERR_ARG;
@@ -189,14 +401,45 @@ int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float*
     const float ks = drop_scale(p);
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((band_attn_fwd_kernel<float>), grid, block, 0, st, (const float*)q, (const float*)k,
-                           (const float*)v, mask, (float*)out, H, L, window, (long)ldq, (long)ldk, (long)ldv,
+                           (const float*)v, mask, (float*)out, lse, H, L, window, (long)ldq, (long)ldk, (long)ldv,
                            (long)ldo, scale, th, ks, seed);
     else if (dtype == CWLT_BF16)
         hipLaunchKernelGGL((band_attn_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                           (const bf16_t*)v, mask, (bf16_t*)out, H, L, window, (long)ldq, (long)ldk, (long)ldv,
+                           (const bf16_t*)v, mask, (bf16_t*)out, lse, H, L, window, (long)ldq, (long)ldk, (long)ldv,
                            (long)ldo, scale, th, ks, seed);
     else
         return CWLT_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+/* Backward of cwlt_band_attn_fwd.  out / lse: the forward's outputs (lse (B, H, L) f32); dout: gradient w.r.t.
+ * out (row stride lddo); dq, dk, dv: gradients w.r.t. the RAW q, k, v, laid out like them with row strides
+ * lddq / lddk / lddv (e.g. the three column blocks of one fused (B*L, 3*H*64) buffer). */
+int cwlt_band_attn_bwd(const void* q, const void* k, const void* v, const float* mask, const void* out,
+                       const float* lse, const void* dout, void* dq, void* dk, void* dv, int B, int H, int L,
+                       int head_dim, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                       int64_t lddq, int64_t lddk, int64_t lddv, float scale, float p, uint64_t seed, int dtype,
+                       void* stream) {
+    using namespace cwlt;
+    if (B < 0 || H <= 0 || L < 0 || head_dim != BD || window < 0 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (B == 0 || L == 0) return CWLT_OK;
+    if (!q || !k || !v || !out || !lse || !dout || !dq || !dk || !dv) return CWLT_ERR_ARG;
+    if ((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 3) return CWLT_ERR_ARG;
+    const dim3 grid((L + BT - 1) / BT, B * H), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t th = drop_thresh(p);
+    const float ks = drop_scale(p);
+#define CWLT_BAND_BWD(T)                                                                                          \
+    hipLaunchKernelGGL((band_attn_bwd_kernel<T, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, \
+                       mask, (const T*)out, (const T*)dout, lse, (T*)dk, (T*)dv, H, L, window, (long)ldq, (long)ldk, \
+                       (long)ldv, (long)ldo, (long)lddo, (long)lddk, (long)lddv, scale, th, ks, seed);            \
+    hipLaunchKernelGGL((band_attn_bwd_kernel<T, false>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, \
+                       mask, (const T*)out, (const T*)dout, lse, (T*)dq, (T*)nullptr, H, L, window, (long)ldq,     \
+                       (long)ldk, (long)ldv, (long)ldo, (long)lddo, (long)lddq, (long)0, scale, th, ks, seed)
+    if (dtype == CWLT_F32) { CWLT_BAND_BWD(float); }
+    else if (dtype == CWLT_BF16) { CWLT_BAND_BWD(bf16_t); }
+    else return CWLT_ERR_DTYPE;
+#undef CWLT_BAND_BWD
     return (int)hipGetLastError();
 }
 

@@ -1,8 +1,8 @@
 """Drop-in for /root/reference/dqn_policy/AIRL.py: `RewardDiscri`, the AIRL reward module around the
-Longformer discriminator.  Scoring (`all_forward`, `calculate_reward`, `update_disc(train=False)`) runs
-on the libcwlt kernels; that is the only mode the RL loop uses (IRL_dqn_train.py:477).  The training
-branch (`train=True`, AIRL.py:135-212) needs the discriminator backward, which is the next widening step
- and raises NotImplementedError here.
+Longformer discriminator, on the libcwlt kernels.  Scoring (`all_forward`, `calculate_reward`,
+`update_disc(train=False)`) is the mode the RL loop uses (IRL_dqn_train.py:477) and runs without autograd; the
+training branch (`train=True`, AIRL.py:135-212) runs the same kernels as autograd Functions (band-attention,
+LN, GELU, embedding and CE backward kernels).  wandb / tqdm / loss plots are not reproduced.
 """
 import os
 import pickle
@@ -82,12 +82,50 @@ class RewardDiscri(nn.Module):
         return pred_val
 
     def update_disc(self, agent_episode, expert_episode, train=True):
-        """AIRL.py:121-236 with train=False: rewards of the agent and expert buffers + the reward pickle."""
-        if train:
-            raise NotImplementedError("discriminator training (AIRL.py:135-212) needs the Longformer backward: "
-                                      "next widening step (SURVEY §8f #3); the RL loop calls train=False")
+        """AIRL.py:121-236: optional discriminator training, then the rewards of the agent and expert buffers +
+        the reward pickle.  Training (AIRL.py:135-212), per batch of 100: BCE(expert score, 1) + BCE(agent score, 0)
+        + token CE of the agent windows against the expert windows, one Adam step and one StepLR step; tails
+        shorter than a batch are dropped.  The checkpoint is written during epoch 0 only (`epoch % 5 == 0` with
+        5 epochs), and `calculate_reward` below reloads that file -- so, as in the reference, the rewards come
+        from the weights as they stood at the end of epoch 0."""
         agent_state_action, _, _, agent_nextstate_action, agent_done = agent_episode
         exp_state_action, _, _, exp_nextstate_action, exp_done, mask_states, mask_next_states = expert_episode
+        self.last_losses = []
+        if train:
+            bs = self.batch_size
+            agent_label = torch.zeros((bs, 1)).float().cuda()
+            exp_label = torch.ones((bs, 1)).float().cuda()
+            n_batch = agent_state_action.shape[0] // bs
+            for epoch in range(self.epoch_disc):
+                sums = torch.zeros(4, device="cuda")
+                for idx in range(n_batch):
+                    s, e = idx * bs, (idx + 1) * bs
+                    self.optim_disc.zero_grad()
+                    st_exp = exp_state_action[s:e].long().cuda()
+                    m_st = mask_states[s:e].long().cuda()
+                    m_nx = mask_next_states[s:e].long().cuda()
+                    exp_logits = self.all_forward(st_exp, exp_done[s:e].long().cuda(),
+                                                  exp_nextstate_action[s:e].long().cuda(), m_st, m_nx)
+                    exp_bce = self.BCE_criterion(exp_logits, exp_label)
+                    st_ag = agent_state_action[s:e].long().cuda()
+                    ce = self.disc_model.token_forward(st_ag, st_exp, m_st)
+                    agent_logits = self.all_forward(st_ag, agent_done[s:e].long().cuda(),
+                                                    agent_nextstate_action[s:e].long().cuda(), m_st, m_nx)
+                    agent_bce = self.BCE_criterion(agent_logits, agent_label)
+                    global_loss = exp_bce + (agent_bce + ce)
+                    global_loss.backward()
+                    self.optim_disc.step()
+                    self.sched_disc.step()
+                    sums += torch.stack([exp_bce.detach(), agent_bce.detach(), ce.detach(), global_loss.detach()])
+                if epoch % 5 == 0 and n_batch:
+                    os.makedirs(os.path.dirname(self.IRL_ckpt_path) or ".", exist_ok=True)
+                    torch.save({"epoch": self.epoch_disc, "model_state_dict": self.disc_model.state_dict(),
+                                "optimizer_state_dict": self.optim_disc.state_dict()}, self.IRL_ckpt_path)
+                if n_batch:
+                    e_l, a_l, c_l, g_l = (sums / n_batch).tolist()
+                    self.last_losses.append({"expert": e_l, "agent": a_l, "ce": c_l, "global": g_l})
+                    print("Epoch:{}/{}| Exp_L:{}| Gene_L:{}| CE_L:{}| Global_L:{}".format(
+                        epoch, self.epoch_disc, e_l, a_l, c_l, g_l))
         traj_reward = self.calculate_reward(agent_state_action, agent_done, agent_nextstate_action, mask_states,
                                             mask_next_states)
         answer_reward = self.calculate_reward(exp_state_action, exp_done, exp_nextstate_action, mask_states,

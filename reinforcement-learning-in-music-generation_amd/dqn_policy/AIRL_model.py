@@ -1,5 +1,6 @@
 """Drop-in for /root/reference/dqn_policy/AIRL_model.py: `LongFormer`, the AIRL discriminator
-(10-layer Longformer, window 50, mean-pool + score classifier), forward on the libcwlt kernels."""
+(10-layer Longformer, window 50, mean-pool + score classifier) on the libcwlt kernels.  Differentiable when
+autograd is enabled (discriminator training, AIRL.py:135-170); scoring callers wrap it in torch.no_grad()."""
 import os
 import sys
 
@@ -34,16 +35,18 @@ class LongFormer(CWLongformerBase):
 
     def forward(self, data, masks):
         """data (B, window, 6), masks (B, window) -> (B, 1) in (0, 1)   (AIRL_model.py:101-122)."""
-        with torch.no_grad():
-            seq = self._encode(data, masks)
-            return self.score_classifier(seq.float().mean(dim=1))
+        seq = self._encode(data, masks)
+        return self.score_classifier(seq.float().mean(dim=1))
 
     def token_forward(self, data, target, loss_mask):
-        """Mean of the 6 token CE losses of the discriminator's heads (AIRL_model.py:131-170), forward only."""
-        with torch.no_grad():
-            h = self._encode(data, loss_mask)
-            logits = self._fused_logits(h)
-            rows = logits.shape[0]
-            ones = torch.ones(rows, device=logits.device)
-            res = ops.heads_forward(logits, self.n_token, target.reshape(rows, len(self.n_token)), ones)
-            return (res["loss_sum"] / rows).sum() / len(self.n_token)
+        """Mean of the 6 token CE losses of the discriminator's heads (AIRL_model.py:131-170).  compute_CEloss
+        there multiplies an already-meaned CE by the mask and divides by its sum, i.e. the plain mean CE."""
+        h = self._encode(data, loss_mask)
+        logits = self._fused_logits(h)
+        rows = logits.shape[0]
+        ones = torch.ones(rows, device=logits.device)
+        tgt = target.reshape(rows, len(self.n_token))
+        if torch.is_grad_enabled():
+            return ops.heads_ce(logits, tgt, ones, self.n_token).sum() / len(self.n_token)
+        res = ops.heads_forward(logits, self.n_token, tgt, ones)
+        return (res["loss_sum"] / rows).sum() / len(self.n_token)

@@ -13,8 +13,10 @@ Semantics restated from transformers' modeling_longformer.py (LongformerEmbeddin
 SelfOutput / Intermediate / Output): position ids start at pad_token_id + 1 = 2, token type 0, LayerNorm eps
 1e-12, post-LN residual blocks, exact-erf gelu, band attention with one-sided window = attention_window/2,
 masked keys excluded, masked query rows zeroed.  `position_embedding_type="relative_key"` is ignored by
-Longformer.  Forward only: scoring is what the RL loops use (`update_disc(train=False)`,
-frozen reward model); discriminator training is listed as the next widening step.
+Longformer.  Two schedules over the same kernels: with autograd off (scoring, what the RL
+loops use: `update_disc(train=False)`, the frozen PPO reward model) nothing is saved; with autograd on
+(discriminator training, dqn_policy/AIRL.py:135-170) the fused blocks run as autograd Functions whose
+backward kernels regenerate the dropout masks from their seeds.
 """
 import torch
 import torch.nn as nn
@@ -100,13 +102,52 @@ class LongformerModel(nn.Module):
         self.max_pos = max_position_embeddings
         self.compute_dtype = torch.float32
 
-    @torch.no_grad()
     def forward(self, inputs_embeds=None, attention_mask=None):
         if inputs_embeds is None:
             raise ValueError("the reference always passes inputs_embeds")
         x = inputs_embeds
         if not x.is_cuda:
             raise RuntimeError("rlmg_amd Longformer runs on the GPU only (no CPU fallback)")
+        if torch.is_grad_enabled():
+            return self._forward_autograd(x, attention_mask)
+        return self._forward_scoring(x, attention_mask)
+
+    def _forward_autograd(self, x, attention_mask):
+        """Training schedule: same arithmetic as `_forward_scoring`, every block differentiable."""
+        B, L, Dm = x.shape
+        if L + 2 > self.max_pos:
+            raise RuntimeError("sequence length %d exceeds max_position_embeddings" % L)
+        adt = self.compute_dtype
+        ph = self.p_hidden if self.training else 0.0
+        pa = self.p_attn if self.training else 0.0
+        seed = lambda p: ops.next_seed() if p > 0 else 0     # noqa: E731
+        emb = self.embeddings
+        add = emb.position_embeddings.weight[emb.padding_idx + 1: emb.padding_idx + 1 + L] \
+            + emb.token_type_embeddings.weight[0]
+        h = (x.float() + add).to(adt).reshape(B * L, Dm)
+        h = ops.AddDropoutLayerNormFn.apply(None, h, emb.LayerNorm.weight, emb.LayerNorm.bias, self.eps, 0.0, 0)
+        if ph > 0:
+            h = ops.PosEncDropoutFn.apply(h.view(B, L, Dm), None, ph, seed(ph)).reshape(B * L, Dm)
+        mask = None if attention_mask is None else attention_mask.reshape(B, L).float()
+        H = self.n_heads
+        for layer in self.encoder.layer:
+            sa = layer.attention.self
+            wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0).to(adt)
+            bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0).to(adt)
+            qkv = F.linear(h, wqkv, bqkv).view(B, L, 3, H, Dm // H)
+            a = ops.BandAttentionFn.apply(qkv, mask, self.one_sided_window, pa, seed(pa)).view(B * L, Dm)
+            ao = layer.attention.output
+            o = F.linear(a, ao.dense.weight.to(adt), ao.dense.bias.to(adt))
+            h1 = ops.AddDropoutLayerNormFn.apply(h, o, ao.LayerNorm.weight, ao.LayerNorm.bias, self.eps, ph, seed(ph))
+            it = layer.intermediate.dense
+            g = ops.BiasGeluDropoutFn.apply(F.linear(h1, it.weight.to(adt)), it.bias, 0.0, 0)
+            lo = layer.output
+            y = F.linear(g, lo.dense.weight.to(adt), lo.dense.bias.to(adt))
+            h = ops.AddDropoutLayerNormFn.apply(h1, y, lo.LayerNorm.weight, lo.LayerNorm.bias, self.eps, ph, seed(ph))
+        return LongformerOutput(h.view(B, L, Dm))
+
+    @torch.no_grad()
+    def _forward_scoring(self, x, attention_mask):
         B, L, Dm = x.shape
         if L + 2 > self.max_pos:
             raise RuntimeError("sequence length %d exceeds max_position_embeddings" % L)

@@ -328,10 +328,11 @@ class PosEncDropoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, pe, p, seed):
         N, T, D = x.shape
-        if T > pe.shape[-2]:
+        if pe is not None and T > pe.shape[-2]:
             raise RuntimeError("sequence length %d exceeds the positional table (%d)" % (T, pe.shape[-2]))
         ctx.p, ctx.seed, ctx.T = p, seed, T
-        return posenc_dropout(x.reshape(N * T, D), pe.reshape(-1, D), T, p, seed).view(N, T, D)
+        return posenc_dropout(x.reshape(N * T, D), None if pe is None else pe.reshape(-1, D), T, p,
+                              seed).view(N, T, D)
 
     @staticmethod
     def backward(ctx, dy):
@@ -457,22 +458,97 @@ def heads_ce(logits, target, mask, n_class):
 
 
 # --------------------------------------------------------------------------------------------------
-# banded attention (AIRL discriminator), forward only
+# banded attention (AIRL discriminator)
 # --------------------------------------------------------------------------------------------------
-def band_attention(q, k, v, mask, window, p=0.0, seed=0):
+def band_attention(q, k, v, mask, window, p=0.0, seed=0, want_lse=False):
     """q, k, v: (B, L, H, 64) views; mask (B, L) nonzero = attend or None; window = one-sided width.
-    -> (B, L, H*64).  Forward only (discriminator scoring; its training is the next widening step)."""
+    -> (B, L, H*64)  [, lse (B, H, L) f32 when want_lse]."""
     B, L, H, D = q.shape
     q, ldq = _as_rows(q)
     k, ldk = _as_rows(k)
     v, ldv = _as_rows(v)
     out = torch.empty((B, L, H * D), dtype=q.dtype, device=q.device)
+    lse = torch.empty((B, H, L), dtype=torch.float32, device=q.device) if want_lse else None
     if mask is not None:
         mask = mask.reshape(B, L).float().contiguous()
     _call("cwlt_band_attn_fwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.opt(mask), _lib.dev(out),
-          B, H, L, D, int(window), ldq, ldk, ldv, H * D, 1.0 / math.sqrt(D), float(p), int(seed),
+          _lib.opt(lse), B, H, L, D, int(window), ldq, ldk, ldv, H * D, 1.0 / math.sqrt(D), float(p), int(seed),
           _lib.dtype_code(q.dtype), _lib.stream_ptr())
-    return out
+    return (out, lse) if want_lse else out
+
+
+class BandAttentionFn(torch.autograd.Function):
+    """Band attention over one fused projection buffer qkv (B, L, 3, H, 64) -> (B, L, H*64); the backward
+    writes the three gradients straight into the column blocks of one (B, L, 3, H, 64) buffer."""
+
+    @staticmethod
+    def forward(ctx, qkv, mask, window, p, seed):
+        qkv = qkv.contiguous()
+        B, L, _, H, D = qkv.shape
+        if mask is not None:
+            mask = mask.reshape(B, L).float().contiguous()
+        out, lse = band_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask, window, p, seed, want_lse=True)
+        ctx.save_for_backward(qkv, out, lse, mask)
+        ctx.cfg = (int(window), float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse, mask = ctx.saved_tensors
+        window, p, seed = ctx.cfg
+        B, L, _, H, D = qkv.shape
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        ld = 3 * H * D
+        views = [_as_rows(t[:, :, i])[0] for t in (qkv, dqkv) for i in range(3)]
+        q, k, v, dq, dk, dv = views
+        if any(t.data_ptr() != src[:, :, i].data_ptr() for src, ts in ((qkv, views[:3]), (dqkv, views[3:]))
+               for i, t in enumerate(ts)):
+            raise RuntimeError("band attention backward needs the fused (B, L, 3, H, 64) layout")
+        _call("cwlt_band_attn_bwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.opt(mask),
+              _lib.dev(out), _lib.dev(lse), _lib.dev(dout, "dout"), _lib.dev(dq, "dq"), _lib.dev(dk, "dk"),
+              _lib.dev(dv, "dv"), B, H, L, D, window, ld, ld, ld, H * D, H * D, ld, ld, ld, 1.0 / math.sqrt(D), p, seed,
+              _lib.dtype_code(qkv.dtype), _lib.stream_ptr())
+        return dqkv, None, None, None, None
+
+
+class AddDropoutLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(a)) (x may be None) -- the post-LN residual block of BertSelfOutput /
+    LongformerOutput, differentiable.  gamma / beta f32."""
+
+    @staticmethod
+    def forward(ctx, x, a, gamma, beta, eps, p, seed):
+        g, b = _f32(gamma), _f32(beta)
+        s, y, mean, rstd = ln_fwd(x, a, g, b, eps, p, seed, save_s=True)
+        ctx.save_for_backward(s, g, mean, rstd)
+        ctx.cfg = (x is not None, float(p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        s, g, mean, rstd = ctx.saved_tensors
+        has_x, p, seed = ctx.cfg
+        ds, da, dg, db, _ = ln_bwd(dy, None, s, g, mean, rstd, p, seed, want_dbias=False)
+        return (ds if has_x else None), da, dg, db, None, None, None
+
+
+class BiasGeluDropoutFn(torch.autograd.Function):
+    """g = dropout(gelu(h + bias)), exact-erf gelu; bias f32."""
+
+    @staticmethod
+    def forward(ctx, h, bias, p, seed):
+        b = _f32(bias)
+        h = h.contiguous()
+        ctx.save_for_backward(h, b)
+        ctx.cfg = (float(p), int(seed))
+        return gelu_fwd(h, b, p, seed)
+
+    @staticmethod
+    def backward(ctx, dg):
+        h, b = ctx.saved_tensors
+        p, seed = ctx.cfg
+        dh, dbias = gelu_bwd(dg, h, b, p, seed, want_dbias=True)
+        return dh, dbias, None, None
 
 
 def recurrent_cla_step(qkv, S, Z, H, eps=CLA_EPS):

@@ -50,6 +50,16 @@ def _import_reference(subdir):
     return config, model
 
 
+def _transformers_placeholders():
+    """AIRL_model.py:10 imports two names that are gone from the transformers release in this image and that
+    nothing uses; give the (lazy, self-replacing) transformers module placeholders for them."""
+    from transformers import LongformerModel  # noqa: F401  -- settles the lazy module object first
+    tf = sys.modules["transformers"]
+    for name in ("TrajectoryTransformerConfig", "TrajectoryTransformerModel"):
+        if not hasattr(tf, name):
+            setattr(tf, name, type(name, (), {}))
+
+
 def _np(sd):
     return {k: v.detach().cpu().numpy() for k, v in sd.items() if k != "pos_emb.pe"}
 
@@ -155,10 +165,7 @@ def airl_small():
     """dqn_policy/AIRL_model.py::LongFormer (AIRL discriminator), eval mode.  Its module-level constants are
     patched to a small net after import; line 10's dead import of TrajectoryTransformer* (gone from the
     transformers release in this image) is satisfied with placeholder names that nothing uses."""
-    import transformers
-    for name in ("TrajectoryTransformerConfig", "TrajectoryTransformerModel"):
-        if not hasattr(transformers, name):
-            setattr(transformers, name, type(name, (), {}))
+    _transformers_placeholders()
     from oracle import ft_standin
     ft_standin.install()
     sys.modules.pop("AIRL_model", None)
@@ -184,6 +191,53 @@ def airl_small():
                         n_class=np.array(n_class), keys=np.array(sorted(net.state_dict().keys())))
 
 
+def airl_grads_small():
+    """Gradients of the discriminator's training loss (dqn_policy/AIRL.py:150-170: BCE(expert, 1) + BCE(agent, 0) +
+    token CE of the agent windows vs the expert windows) through the reference's own AIRL_model.LongFormer + HF
+    Longformer, eval mode (dropout off, BatchNorm running statistics) so that it is deterministic.  Stored: the
+    three loss terms, the L2 norm of every parameter's gradient, and the gradient itself (first 8 rows of
+    tensors with more than 4096 elements) for every parameter."""
+    _transformers_placeholders()
+    from oracle import ft_standin
+    ft_standin.install()
+    sys.modules.pop("AIRL_model", None)
+    path = os.path.join(REF, "dqn_policy")
+    sys.path.insert(0, path)
+    try:
+        am = importlib.import_module("AIRL_model")
+    finally:
+        sys.path.remove(path)
+    am.D_MODEL, am.N_LAYER, am.N_HEAD = 128, 2, 2
+    n_class = [56, 135, 18, 87, 18, 25]
+    net = fill_params(am.LongFormer(n_class), seed=43).eval()
+    with torch.no_grad():
+        net.score_classifier[1].running_mean.copy_(torch.linspace(-0.2, 0.2, 128))
+        net.score_classifier[1].running_var.copy_(torch.linspace(0.5, 1.5, 128))
+    gen = torch.Generator().manual_seed(79)
+    x_exp = _tokens(gen, (3, 50), n_class)
+    x_agent = _tokens(gen, (3, 50), n_class)
+    mask = torch.ones(3, 50, dtype=torch.long)
+    mask[1, 44:] = 0
+    bce = torch.nn.BCELoss()
+    exp_l = bce(net(x_exp, mask), torch.ones(3, 1))
+    ce_l = net.token_forward(x_agent, x_exp, mask)
+    agent_l = bce(net(x_agent, mask), torch.zeros(3, 1))
+    (exp_l + (agent_l + ce_l)).backward()
+    out = {"x_exp": x_exp.numpy(), "x_agent": x_agent.numpy(), "mask": mask.numpy(), "n_class": np.array(n_class),
+           "losses": np.array([exp_l.item(), agent_l.item(), ce_l.item()], dtype=np.float64)}
+    names, norms = [], []
+    for k, p_ in net.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad.detach()
+        names.append(k)
+        norms.append(g.double().norm().item())
+        out["grad." + k] = (g[:8] if g.numel() > 4096 else g).numpy()
+    out["names"] = np.array(names)
+    out["norms"] = np.array(norms)
+    np.savez_compressed(os.path.join(HERE, "airl_grads_small.npz"), **out)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     dqn_small()
@@ -191,6 +245,7 @@ if __name__ == "__main__":
     ppo_small()
     ppo_reward_small()
     airl_small()
+    airl_grads_small()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
