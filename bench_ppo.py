@@ -44,12 +44,15 @@ def main():
     ap.add_argument("--iters", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graphs", action="store_true", help="launch the rollout step eagerly (no hipGraph)")
     args = ap.parse_args()
 
     import rlmg_amd  # noqa: F401
     from rlmg_amd import dist as rdist, gemm_tuning, ops, rl_ops
     from rlmg_amd.ppo_policy import ppo_train as P
 
+    if args.no_graphs:
+        ops.GRAPHS_ENABLED = False
     rank, local, world = rdist.init_from_env()
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
@@ -81,12 +84,9 @@ def main():
         rewards = torch.empty((E, R), dtype=torch.float32, device=dev)
         with torch.no_grad():
             for t in range(E):
-                action, logp = agent.choose_action(state)                       # (R, NA, 6)
-                if R == 1:
-                    action, logp = action.unsqueeze(0), logp.unsqueeze(0)
-                state = torch.cat((state[:, :NA], action), dim=1)               # next_state (ppo_train.py:483)
-                values[t] = agent.critic_net.value_produce(state).reshape(R)
-                rewards[t] = agent.eval_net.token_forward(state, None, mask[:, t:t + W]).reshape(R)
+                # actor action -> next state -> critic value -> reward model: one hipGraph replay per step
+                _, logp, state, value, reward = agent.rollout_step(state, mask[:, t:t + W])
+                values[t], rewards[t] = value.reshape(R), reward.reshape(R)
                 states[t], logps[t] = state, logp
         torch.cuda.synchronize()
         t_roll = time.perf_counter() - t_roll0
@@ -143,7 +143,7 @@ def main():
             "rollout_only_env_steps_per_s": round(steps / t_roll, 2),
             "config": {"workload": "ppo_train iteration: %d rollouts/GPU x window %d, EPISODES %d, PPO_STEPS %d, "
                                    "actor/critic 512/12/8, reward Longformer 512/12/8 w=512" % (R, W, E, args.ppo_steps),
-                       "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
+                       "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
                        "parallelism": "dp%d" % world}}), flush=True)
     if world > 1:
         torch.distributed.barrier()

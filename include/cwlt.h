@@ -76,12 +76,16 @@ int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const
  *   x = x + self.dropout(attn(...)); x = self.norm1(x); ... ; self.norm2(x + self.dropout(ffn));
  * and TransformerEncoder's final self.norm(x) (x == NULL, p == 0).
  * x may be NULL (plain LayerNorm of a); s_out may be NULL; mean/rstd (rows) f32 are saved stats.
- * D % 8 == 0, D <= 1024.  Dropout masks are regenerated from (seed, element index) in backward. */
+ * D % 8 == 0, D <= 1024.  Dropout masks are regenerated from (seed, element index) in backward.
+ * seed_base (every entry point that takes a seed): optional device pointer to one uint64 that the kernel adds
+ * to `seed` when it runs (NULL = 0).  `seed` is baked into a captured hipGraph; bumping *seed_base between
+ * replays (itself a captured device op) gives each replay fresh masks.  Forward and backward of one op must
+ * see the same seed + *seed_base. */
 int cwlt_ln_blocks(int64_t rows);
 int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* gamma, const float* beta,
                                    void* s_out, void* y, float* mean, float* rstd,
                                    int64_t rows, int D, float eps, float p, uint64_t seed,
-                                   int dtype, void* stream);
+                                   const uint64_t* seed_base, int dtype, void* stream);
 /* dy2 (optional second upstream gradient, summed with dy), ds = d/ds (also the residual gradient),
  * da = dropout-masked ds (NULL when p == 0: then da == ds).  part: cwlt_ln_blocks(rows)*3*D f32
  * workspace; stats: (3, D) f32 output = dgamma | dbeta | dbias, where dbias = column sum of da,
@@ -89,7 +93,8 @@ int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* ga
 int cwlt_add_dropout_layernorm_bwd(const void* dy, const void* dy2, const void* s, const float* gamma,
                                    const float* mean, const float* rstd, void* ds, void* da,
                                    float* part, float* stats,
-                                   int64_t rows, int D, float p, uint64_t seed, int dtype, void* stream);
+                                   int64_t rows, int D, float p, uint64_t seed, const uint64_t* seed_base,
+                                   int dtype, void* stream);
 
 /* ---- deterministic column sums (bias gradients) -------------------------------------------------
  * out[c] = sum_r x[r*ld + c]; part: cwlt_colsum_blocks(rows)*ncols f32.  Replaces the reductions
@@ -103,19 +108,19 @@ int cwlt_colsum(const void* x, float* part, float* out, int64_t rows, int ncols,
  * dqn_policy/model.py:134) with the Linear run bias-free.  bias may be NULL.  F % 8 == 0. */
 int cwlt_rowslab_blocks(int64_t rows);
 int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_t rows, int F,
-                               float p, uint64_t seed, int dtype, void* stream);
+                               float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
 /* dh = dropout_bwd(dg) * gelu'(h + bias); dbias (F) f32 = column sums of dh (NULL to skip);
  * part: cwlt_rowslab_blocks(rows)*F f32 (needed iff dbias). */
 int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias, void* dh,
                                float* part, float* dbias, int64_t rows, int F, float p,
-                               uint64_t seed, int dtype, void* stream);
+                               uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
 
 /* ---- positional encoding + dropout --------------------------------------------------------------
  * y = dropout_p(x + pe[r % T]) -- PositionalEncoding.forward, dqn_policy/model.py:90-92.  pe is the
  * registered (max_len, D) f32 buffer; pe == NULL gives plain dropout, which is also this op's
  * backward (dx = dropout with the same seed applied to dy). */
 int cwlt_posenc_dropout(const void* x, const float* pe, void* y, int64_t rows, int T, int D,
-                        float p, uint64_t seed, int dtype, void* stream);
+                        float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
 
 /* ---- compound-word multi-embedding --------------------------------------------------------------
  * out[r, off_f : off_f+width_f] = table_f[tokens[r, f]] * sqrt(width_f), f = 0..n_attr-1.
@@ -159,7 +164,7 @@ int cwlt_heads_ce_bwd(const void* logits, const int* n_class, int n_attr, const 
 int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, float* lse,
                        int B, int H, int L, int head_dim, int window,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                       float scale, float p, uint64_t seed, int dtype, void* stream);
+                       float scale, float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
 
 /* Backward of cwlt_band_attn_fwd -- what torch autograd derives through HF LongformerSelfAttention when the
  * reference trains the discriminator (dqn_policy/AIRL.py:135-170, global_loss.backward()).  lse (B, H, L) f32 =
@@ -172,7 +177,7 @@ int cwlt_band_attn_bwd(const void* q, const void* k, const void* v, const float*
                        int B, int H, int L, int head_dim, int window,
                        int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                        int64_t lddq, int64_t lddk, int64_t lddv,
-                       float scale, float p, uint64_t seed, int dtype, void* stream);
+                       float scale, float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
 
 /* Gradient of sum_{r,f} w[r][f] * log softmax_f(logits_r)[target[r][f]] w.r.t. the logits, given as the kernel
  * form dlogits = (softmax - onehot(target)) * w: pass w = -(upstream gradient).  Used for the PPO log pi(a)

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -28,19 +28,19 @@ _SIGNATURES = {
     "cwlt_causal_linear_bwd_dkdv": [_ptr] * 10 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr],
     "cwlt_causal_linear_bwd_dq": [_ptr] * 8 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr],
     "cwlt_ln_blocks": [_c_i64],
-    "cwlt_add_dropout_layernorm_fwd": [_ptr] * 8 + [_c_i64, _c_int, _c_f32, _c_f32, _c_u64, _c_int, _ptr],
-    "cwlt_add_dropout_layernorm_bwd": [_ptr] * 10 + [_c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_add_dropout_layernorm_fwd": [_ptr] * 8 + [_c_i64, _c_int, _c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
+    "cwlt_add_dropout_layernorm_bwd": [_ptr] * 10 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_colsum_blocks": [_c_i64],
     "cwlt_colsum": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_i64, _c_int, _ptr],
     "cwlt_rowslab_blocks": [_c_i64],
-    "cwlt_bias_gelu_dropout_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],
-    "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _c_int, _ptr],
-    "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_bias_gelu_dropout_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
+    "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
+    "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_embed_splits": [_c_i64],
     "cwlt_cw_embed_fwd": [_ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_cw_embed_bwd": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
-    "cwlt_band_attn_fwd": [_ptr] * 6 + [_c_int] * 5 + [_c_i64] * 4 + [_c_f32, _c_f32, _c_u64, _c_int, _ptr],
-    "cwlt_band_attn_bwd": [_ptr] * 10 + [_c_int] * 5 + [_c_i64] * 8 + [_c_f32, _c_f32, _c_u64, _c_int, _ptr],
+    "cwlt_band_attn_fwd": [_ptr] * 6 + [_c_int] * 5 + [_c_i64] * 4 + [_c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
+    "cwlt_band_attn_bwd": [_ptr] * 10 + [_c_int] * 5 + [_c_i64] * 8 + [_c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_wgrad_splits": [_c_i64, _c_int, _c_int],
     "cwlt_wgrad_bf16": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_recurrent_cla_step": [_ptr] * 6 + [_c_int] * 3 + [_c_i64] * 4 + [_c_f32, _c_int, _ptr],

@@ -28,7 +28,9 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(const T* __restrict_
                                                             const T* __restrict__ v, const float* __restrict__ mask,
                                                             T* __restrict__ out, float* __restrict__ lse, int H, int L,
                                                             int w, long ldq, long ldk, long ldv, long ldo, float scale,
-                                                            uint32_t thresh, float keep_scale, uint64_t seed) {
+                                                            uint32_t thresh, float keep_scale, uint64_t seed,
+        const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     __shared__ float qs[BT * BLD];
     __shared__ float ks[BT * BLD];
     __shared__ float vs[BT * BLD];
@@ -187,7 +189,9 @@ __global__ __launch_bounds__(256) void band_attn_bwd_kernel(const T* __restrict_
                                                             T* __restrict__ g2, int H, int L, int w, long ldq, long ldk,
                                                             long ldv, long ldo, long lddo, long ldg1, long ldg2,
                                                             float scale, uint32_t thresh, float keep_scale,
-                                                            uint64_t seed) {
+                                                            uint64_t seed,
+        const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     // "own" tile = the 64 rows this workgroup produces gradients for (queries for dq, keys for dk/dv);
     // "other" tile = the rows it loops over.
     __shared__ float a_s[BT * BLD];   // own tile, first operand  (dq: q*scale   | dkdv: k)
@@ -390,7 +394,7 @@ extern "C" {
  * (HF attention_window / 2).  p = dropout on the attention probabilities (0 in eval). */
 int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float* mask, void* out, float* lse, int B,
                        int H, int L, int head_dim, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                       float scale, float p, uint64_t seed, int dtype, void* stream) {
+                       float scale, float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream) {
     using namespace cwlt;
     if (!q || !k || !v || !out || B < 0 || H <= 0 || L < 0 || head_dim != BD || window < 0) return CWLT_ERR_ARG;
     if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
@@ -402,11 +406,11 @@ int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float*
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((band_attn_fwd_kernel<float>), grid, block, 0, st, (const float*)q, (const float*)k,
                            (const float*)v, mask, (float*)out, lse, H, L, window, (long)ldq, (long)ldk, (long)ldv,
-                           (long)ldo, scale, th, ks, seed);
+                           (long)ldo, scale, th, ks, seed, seed_base);
     else if (dtype == CWLT_BF16)
         hipLaunchKernelGGL((band_attn_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, mask, (bf16_t*)out, lse, H, L, window, (long)ldq, (long)ldk, (long)ldv,
-                           (long)ldo, scale, th, ks, seed);
+                           (long)ldo, scale, th, ks, seed, seed_base);
     else
         return CWLT_ERR_DTYPE;
     return (int)hipGetLastError();
@@ -418,7 +422,7 @@ int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float*
 int cwlt_band_attn_bwd(const void* q, const void* k, const void* v, const float* mask, const void* out,
                        const float* lse, const void* dout, void* dq, void* dk, void* dv, int B, int H, int L,
                        int head_dim, int window, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
-                       int64_t lddq, int64_t lddk, int64_t lddv, float scale, float p, uint64_t seed, int dtype,
+                       int64_t lddq, int64_t lddk, int64_t lddv, float scale, float p, uint64_t seed, const uint64_t* seed_base, int dtype,
                        void* stream) {
     using namespace cwlt;
     if (B < 0 || H <= 0 || L < 0 || head_dim != BD || window < 0 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
@@ -432,10 +436,10 @@ int cwlt_band_attn_bwd(const void* q, const void* k, const void* v, const float*
 #define CWLT_BAND_BWD(T)                                                                                          \
     hipLaunchKernelGGL((band_attn_bwd_kernel<T, true>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, \
                        mask, (const T*)out, (const T*)dout, lse, (T*)dk, (T*)dv, H, L, window, (long)ldq, (long)ldk, \
-                       (long)ldv, (long)ldo, (long)lddo, (long)lddk, (long)lddv, scale, th, ks, seed);            \
+                       (long)ldv, (long)ldo, (long)lddo, (long)lddk, (long)lddv, scale, th, ks, seed, seed_base);            \
     hipLaunchKernelGGL((band_attn_bwd_kernel<T, false>), grid, block, 0, st, (const T*)q, (const T*)k, (const T*)v, \
                        mask, (const T*)out, (const T*)dout, lse, (T*)dq, (T*)nullptr, H, L, window, (long)ldq,     \
-                       (long)ldk, (long)ldv, (long)ldo, (long)lddo, (long)lddq, (long)0, scale, th, ks, seed)
+                       (long)ldk, (long)ldv, (long)ldo, (long)lddo, (long)lddq, (long)0, scale, th, ks, seed, seed_base)
     if (dtype == CWLT_F32) { CWLT_BAND_BWD(float); }
     else if (dtype == CWLT_BF16) { CWLT_BAND_BWD(bf16_t); }
     else return CWLT_ERR_DTYPE;

@@ -48,7 +48,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* __restrict__ h,
                                                                     const float* __restrict__ bias, T* __restrict__ g,
                                                                     long rows, int F, uint32_t thresh, float keep_scale,
-                                                                    uint64_t seed) {
+                                                                    uint64_t seed,
+        const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     constexpr int V = VecIO<T>::N;
     constexpr bool FAST = sizeof(T) == 2;
     const int ci = blockIdx.x * 256 + threadIdx.x;
@@ -78,7 +80,9 @@ template <typename T>
 __global__ __launch_bounds__(256) void bias_gelu_dropout_bwd_kernel(const T* __restrict__ dg, const T* __restrict__ h,
                                                                     const float* __restrict__ bias, T* __restrict__ dh,
                                                                     float* __restrict__ part, long rows, int F,
-                                                                    uint32_t thresh, float keep_scale, uint64_t seed) {
+                                                                    uint32_t thresh, float keep_scale, uint64_t seed,
+        const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     constexpr int V = VecIO<T>::N;
     constexpr bool FAST = sizeof(T) == 2;
     const int ci = blockIdx.x * 256 + threadIdx.x;
@@ -113,7 +117,9 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_bwd_kernel(const T* __r
 template <typename T>
 __global__ __launch_bounds__(256) void posenc_dropout_kernel(const T* __restrict__ x, const float* __restrict__ pe,
                                                              T* __restrict__ y, long rows, int Tlen, int D,
-                                                             uint32_t thresh, float keep_scale, uint64_t seed) {
+                                                             uint32_t thresh, float keep_scale, uint64_t seed,
+        const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     constexpr int V = VecIO<T>::N;
     const int nd = D / V;
     const long nv = rows * (long)nd;
@@ -149,7 +155,7 @@ int cwlt_rowslab_blocks(int64_t rows) {
 }
 
 int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_t rows, int F, float p, uint64_t seed,
-                               int dtype, void* stream) {
+                               const uint64_t* seed_base, int dtype, void* stream) {
     using namespace cwlt;
     if (!h || !g || rows < 0 || F <= 0 || (F & 7) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
@@ -160,10 +166,10 @@ int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_
     const float ks = drop_scale(p);
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((bias_gelu_dropout_fwd_kernel<float>), grid, block, 0, st, (const float*)h, bias, (float*)g,
-                           (long)rows, F, th, ks, seed);
+                           (long)rows, F, th, ks, seed, seed_base);
     else if (dtype == CWLT_BF16)
         hipLaunchKernelGGL((bias_gelu_dropout_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)h, bias,
-                           (bf16_t*)g, (long)rows, F, th, ks, seed);
+                           (bf16_t*)g, (long)rows, F, th, ks, seed, seed_base);
     else
         return CWLT_ERR_DTYPE;
     return (int)hipGetLastError();
@@ -171,7 +177,7 @@ int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_
 
 /* part: cwlt_rowslab_blocks(rows) * F floats (only if dbias != NULL); dbias (F) f32 = column sums of dh. */
 int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias, void* dh, float* part, float* dbias,
-                               int64_t rows, int F, float p, uint64_t seed, int dtype, void* stream) {
+                               int64_t rows, int F, float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream) {
     using namespace cwlt;
     if (!dg || !h || !dh || rows < 0 || F <= 0 || (F & 7) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (dbias && !part) return CWLT_ERR_ARG;
@@ -185,10 +191,10 @@ int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias,
     float* pp = dbias ? part : nullptr;
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((bias_gelu_dropout_bwd_kernel<float>), grid, block, 0, st, (const float*)dg, (const float*)h,
-                           bias, (float*)dh, pp, (long)rows, F, th, ks, seed);
+                           bias, (float*)dh, pp, (long)rows, F, th, ks, seed, seed_base);
     else if (dtype == CWLT_BF16)
         hipLaunchKernelGGL((bias_gelu_dropout_bwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)dg,
-                           (const bf16_t*)h, bias, (bf16_t*)dh, pp, (long)rows, F, th, ks, seed);
+                           (const bf16_t*)h, bias, (bf16_t*)dh, pp, (long)rows, F, th, ks, seed, seed_base);
     else
         return CWLT_ERR_DTYPE;
     int e = (int)hipGetLastError();
@@ -198,7 +204,7 @@ int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias,
 
 /* y = dropout(x + pe[r % T]); pe may be NULL (plain dropout; also the backward of this op with dy as x). */
 int cwlt_posenc_dropout(const void* x, const float* pe, void* y, int64_t rows, int T, int D, float p, uint64_t seed,
-                        int dtype, void* stream) {
+                        const uint64_t* seed_base, int dtype, void* stream) {
     using namespace cwlt;
     if (!x || !y || rows < 0 || D <= 0 || (D & 7) || T <= 0 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
@@ -210,10 +216,10 @@ int cwlt_posenc_dropout(const void* x, const float* pe, void* y, int64_t rows, i
     const float ks = drop_scale(p);
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((posenc_dropout_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)x, pe, (float*)y,
-                           (long)rows, T, D, th, ks, seed);
+                           (long)rows, T, D, th, ks, seed, seed_base);
     else if (dtype == CWLT_BF16)
         hipLaunchKernelGGL((posenc_dropout_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)x, pe,
-                           (bf16_t*)y, (long)rows, T, D, th, ks, seed);
+                           (bf16_t*)y, (long)rows, T, D, th, ks, seed, seed_base);
     else
         return CWLT_ERR_DTYPE;
     return (int)hipGetLastError();

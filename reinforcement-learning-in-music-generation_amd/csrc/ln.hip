@@ -19,7 +19,9 @@ __global__ __launch_bounds__(256) void add_dropout_ln_fwd_kernel(const T* __rest
                                                                  const float* __restrict__ beta, T* __restrict__ s_out,
                                                                  T* __restrict__ y, float* __restrict__ mean,
                                                                  float* __restrict__ rstd, long rows, int D, float eps,
-                                                                 uint32_t thresh, float keep_scale, uint64_t seed) {
+                                                                 uint32_t thresh, float keep_scale, uint64_t seed,
+        const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     constexpr int V = VecIO<T>::N;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nchunk = D / V;
@@ -97,7 +99,9 @@ __global__ __launch_bounds__(256) void add_dropout_ln_bwd_kernel(const T* __rest
                                                                  const float* __restrict__ rstd, T* __restrict__ ds,
                                                                  T* __restrict__ da, float* __restrict__ part,
                                                                  long rows, int D, uint32_t thresh, float keep_scale,
-                                                                 uint64_t seed) {
+                                                                 uint64_t seed,
+        const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     constexpr int V = VecIO<T>::N;
     __shared__ float red[4][NC * 64 * V];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -274,7 +278,7 @@ int cwlt_ln_blocks(int64_t rows) {
 
 int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* gamma, const float* beta, void* s_out,
                                    void* y, float* mean, float* rstd, int64_t rows, int D, float eps, float p,
-                                   uint64_t seed, int dtype, void* stream) {
+                                   uint64_t seed, const uint64_t* seed_base, int dtype, void* stream) {
     using namespace cwlt;
     if (!a || !gamma || !beta || !y || !mean || !rstd) return CWLT_ERR_ARG;
     if (rows < 0 || D <= 0 || (D & 7) || D > 1024 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
@@ -285,7 +289,7 @@ int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* ga
     hipStream_t st = (hipStream_t)stream;
 #define CWLT_LN_FWD(T, NC)                                                                                       \
     hipLaunchKernelGGL((add_dropout_ln_fwd_kernel<T, NC>), grid, block, 0, st, (const T*)x, (const T*)a, gamma, \
-                       beta, (T*)s_out, (T*)y, mean, rstd, (long)rows, D, eps, th, ks, seed)
+                       beta, (T*)s_out, (T*)y, mean, rstd, (long)rows, D, eps, th, ks, seed, seed_base)
     if (dtype == CWLT_F32) {
         const int nc = ln_nc<float>(D);
         if (nc == 1) CWLT_LN_FWD(float, 1); else if (nc == 2) CWLT_LN_FWD(float, 2); else CWLT_LN_FWD(float, 4);
@@ -303,7 +307,7 @@ int cwlt_add_dropout_layernorm_fwd(const void* x, const void* a, const float* ga
  * dgamma | dbeta | dbias (dbias = column sum of da = bias gradient of the Linear that produced `a`). */
 int cwlt_add_dropout_layernorm_bwd(const void* dy, const void* dy2, const void* s, const float* gamma,
                                    const float* mean, const float* rstd, void* ds, void* da, float* part,
-                                   float* stats, int64_t rows, int D, float p, uint64_t seed, int dtype,
+                                   float* stats, int64_t rows, int D, float p, uint64_t seed, const uint64_t* seed_base, int dtype,
                                    void* stream) {
     using namespace cwlt;
     if (!dy || !s || !gamma || !mean || !rstd || !part || !stats) return CWLT_ERR_ARG;
@@ -316,7 +320,7 @@ int cwlt_add_dropout_layernorm_bwd(const void* dy, const void* dy2, const void* 
     const dim3 grid(nb), block(256);
 #define CWLT_LN_BWD(T, NC)                                                                                        \
     hipLaunchKernelGGL((add_dropout_ln_bwd_kernel<T, NC>), grid, block, 0, st, (const T*)dy, (const T*)dy2,      \
-                       (const T*)s, gamma, mean, rstd, (T*)ds, (T*)da, part, (long)rows, D, th, ks, seed)
+                       (const T*)s, gamma, mean, rstd, (T*)ds, (T*)da, part, (long)rows, D, th, ks, seed, seed_base)
     if (dtype == CWLT_F32) {
         const int nc = ln_nc<float>(D);
         if (nc == 1) CWLT_LN_BWD(float, 1); else if (nc == 2) CWLT_LN_BWD(float, 2); else CWLT_LN_BWD(float, 4);

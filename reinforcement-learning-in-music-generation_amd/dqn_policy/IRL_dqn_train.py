@@ -94,15 +94,25 @@ class DQN(object):
     def _fused(self, net, x):
         return net.fused_logits(net.forward_hidden(x)).view(x.shape[0], x.shape[1], -1)
 
-    def choose_action(self, x, target=None):
-        """(R, 50, 6) -> (25, 6) greedy CW tokens at positions [0, -1, ..., -24] (the reference's `-idx`
-        indexing, IRL_dqn_train.py:256-258); (R, 25, 6) for a batch of R states."""
+    def _choose_action_device(self, x):
         with torch.no_grad():
             logits = self._fused(self.eval_net, x)
             B, T, W = logits.shape
             ids = ops.heads_forward(logits.view(B * T, W), self.n_class, want_argmax=True)["argmax"].view(B, T, -1)
             action, _ = rl_ops.rollout_gather(ids, None, self.n_class, N_ACTIONS, mode=0)
-        return action[0] if B == 1 else action
+        return action
+
+    def choose_action(self, x, target=None):
+        """(R, 50, 6) -> (25, 6) greedy CW tokens at positions [0, -1, ..., -24] (the reference's `-idx`
+        indexing, IRL_dqn_train.py:256-258); (R, 25, 6) for a batch of R states.  The ~300 launches of the
+        50-token forward are replayed as one hipGraph (ops.GraphedCall; CWLT_GRAPHS=0 launches them eagerly)."""
+        if ops.GRAPHS_ENABLED:
+            if getattr(self, "_graph_choose", None) is None:
+                self._graph_choose = ops.GraphedCall(self._choose_action_device)
+            action = self._graph_choose(x).clone()
+        else:
+            action = self._choose_action_device(x)
+        return action[0] if x.shape[0] == 1 else action
 
     def update(self, agent_transition, expert_transition, mask_next_states, update_flag, epoch):
         if self.target_count % Target_update == 0:

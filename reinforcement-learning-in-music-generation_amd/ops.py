@@ -3,6 +3,7 @@
 Everything here runs on the GPU through the C-ABI in include/cwlt.h; there is no CPU path.
 """
 import math
+import os
 
 import torch
 
@@ -111,6 +112,79 @@ def next_seed():
     return int(torch.empty((), dtype=torch.int64).random_().item()) & ((1 << 62) - 1)
 
 
+# A captured hipGraph bakes every kernel argument, dropout seeds included.  The dropout kernels therefore accept
+# an optional device pointer to one uint64 that is ADDED to the seed when the kernel runs (include/cwlt.h,
+# "seed_base").  It is passed only while `GraphedCall` captures (and warms up) a function; the captured graph
+# starts by bumping the value, so every replay draws fresh masks.  Eager launches pass NULL.
+_SEED_BASE = {}
+_USE_SEED_BASE = False
+_SEED_STEP = 0x9E3779B97F4A7C15 - (1 << 64)     # golden-ratio increment as a signed 64-bit integer
+
+
+def seed_base_tensor(device=None):
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    t = _SEED_BASE.get(idx)
+    if t is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError("seed base must exist before graph capture starts")
+        t = torch.zeros(1, dtype=torch.int64, device=torch.device("cuda", idx))
+        _SEED_BASE[idx] = t
+    return t
+
+
+def _seed_base():
+    return _lib.dev(seed_base_tensor()) if _USE_SEED_BASE else None
+
+
+GRAPHS_ENABLED = os.environ.get("CWLT_GRAPHS", "1") != "0"     # CWLT_GRAPHS=0: RL rollout steps launch eagerly
+
+
+class GraphedCall:
+    """Run `fn(*tensors)` -- a no-grad, sync-free function of device tensors (an RL rollout step: trunk forward +
+    heads + action gather, a few hundred launches for a 50-token window) -- as ONE hipGraph launch.  Captured once
+    per input signature; replays copy the arguments into the graph's static inputs, bump the dropout seed base
+    (a captured op) and launch.  Parameters are read in place, so optimizer steps between replays are seen.
+    Outputs are the graph's static buffers: valid until the next call with the same signature."""
+
+    def __init__(self, fn, warmup=2):
+        self.fn, self.warmup, self.graphs = fn, warmup, {}
+
+    def _capture(self, args):
+        global _USE_SEED_BASE
+        dev = args[0].device
+        base = seed_base_tensor(dev)
+        static = [a.clone() for a in args]
+        was_timing = KernelTimer.enabled
+        KernelTimer.enabled = False
+        _USE_SEED_BASE = True
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side), torch.no_grad():
+                for _ in range(self.warmup):
+                    self.fn(*static)
+            torch.cuda.current_stream(dev).wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph), torch.no_grad():
+                base.add_(_SEED_STEP)
+                out = self.fn(*static)
+        finally:
+            _USE_SEED_BASE = False
+            KernelTimer.enabled = was_timing
+        return graph, static, out
+
+    def __call__(self, *args):
+        key = tuple((tuple(a.shape), a.dtype, a.device.index) for a in args)
+        ent = self.graphs.get(key)
+        if ent is None:
+            ent = self.graphs[key] = self._capture(args)
+        graph, static, out = ent
+        for s, a in zip(static, args):
+            s.copy_(a)
+        graph.replay()
+        return out
+
+
 # --------------------------------------------------------------------------------------------------
 # causal linear attention
 # --------------------------------------------------------------------------------------------------
@@ -201,7 +275,7 @@ def ln_fwd(x, a, gamma, beta, eps=LN_EPS, p=0.0, seed=0, save_s=True):
     mean = torch.empty(rows, dtype=torch.float32, device=a.device)
     rstd = torch.empty(rows, dtype=torch.float32, device=a.device)
     _call("cwlt_add_dropout_layernorm_fwd", _lib.opt(x), _lib.dev(a, "a"), _lib.dev(gamma), _lib.dev(beta), _lib.opt(s), _lib.dev(y),
-        _lib.dev(mean), _lib.dev(rstd), rows, D, float(eps), float(p), int(seed),
+        _lib.dev(mean), _lib.dev(rstd), rows, D, float(eps), float(p), int(seed), _seed_base(),
         _lib.dtype_code(a.dtype), _lib.stream_ptr())
     if save_s and s is None:
         s = a
@@ -221,7 +295,7 @@ def ln_bwd(dy, dy2, s, gamma, mean, rstd, p=0.0, seed=0, want_dbias=True):
     part = torch.empty(nb * 3 * D, dtype=torch.float32, device=s.device)
     stats = torch.empty((3, D), dtype=torch.float32, device=s.device)
     _call("cwlt_add_dropout_layernorm_bwd", _lib.dev(dy, "dy"), _lib.opt(dy2), _lib.dev(s), _lib.dev(gamma), _lib.dev(mean), _lib.dev(rstd),
-        _lib.dev(ds), _lib.dev(da) if p > 0 else None, _lib.dev(part), _lib.dev(stats), rows, D, float(p), int(seed),
+        _lib.dev(ds), _lib.dev(da) if p > 0 else None, _lib.dev(part), _lib.dev(stats), rows, D, float(p), int(seed), _seed_base(),
         _lib.dtype_code(s.dtype), _lib.stream_ptr())
     return ds, da, stats[0], stats[1], (stats[2] if want_dbias else None)
 
@@ -257,7 +331,7 @@ def gelu_fwd(h, bias, p=0.0, seed=0):
     rows, F = h.shape
     g = torch.empty_like(h)
     _call("cwlt_bias_gelu_dropout_fwd", _lib.dev(h, "h"), _lib.opt(bias), _lib.dev(g), rows, F, float(p),
-                                              int(seed), _lib.dtype_code(h.dtype), _lib.stream_ptr())
+                                              int(seed), _seed_base(), _lib.dtype_code(h.dtype), _lib.stream_ptr())
     return g
 
 
@@ -271,7 +345,7 @@ def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
         part = torch.empty(lib.cwlt_rowslab_blocks(rows) * F, dtype=torch.float32, device=h.device)
         dbias = torch.empty(F, dtype=torch.float32, device=h.device)
     _call("cwlt_bias_gelu_dropout_bwd", _lib.dev(dg, "dg"), _lib.dev(h), _lib.opt(bias), _lib.dev(dh),
-                                              _lib.opt(part), _lib.opt(dbias), rows, F, float(p), int(seed),
+                                              _lib.opt(part), _lib.opt(dbias), rows, F, float(p), int(seed), _seed_base(),
                                               _lib.dtype_code(h.dtype), _lib.stream_ptr())
     return dh, dbias
 
@@ -318,7 +392,7 @@ def posenc_dropout(x, pe, T, p=0.0, seed=0):
     x = x.contiguous()
     y = torch.empty_like(x)
     _call("cwlt_posenc_dropout", _lib.dev(x, "x"), _lib.opt(pe), _lib.dev(y), rows, int(T), D, float(p),
-                                       int(seed), _lib.dtype_code(x.dtype), _lib.stream_ptr())
+                                       int(seed), _seed_base(), _lib.dtype_code(x.dtype), _lib.stream_ptr())
     return y
 
 
@@ -472,7 +546,7 @@ def band_attention(q, k, v, mask, window, p=0.0, seed=0, want_lse=False):
     if mask is not None:
         mask = mask.reshape(B, L).float().contiguous()
     _call("cwlt_band_attn_fwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.opt(mask), _lib.dev(out),
-          _lib.opt(lse), B, H, L, D, int(window), ldq, ldk, ldv, H * D, 1.0 / math.sqrt(D), float(p), int(seed),
+          _lib.opt(lse), B, H, L, D, int(window), ldq, ldk, ldv, H * D, 1.0 / math.sqrt(D), float(p), int(seed), _seed_base(),
           _lib.dtype_code(q.dtype), _lib.stream_ptr())
     return (out, lse) if want_lse else out
 
@@ -507,7 +581,7 @@ class BandAttentionFn(torch.autograd.Function):
             raise RuntimeError("band attention backward needs the fused (B, L, 3, H, 64) layout")
         _call("cwlt_band_attn_bwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.opt(mask),
               _lib.dev(out), _lib.dev(lse), _lib.dev(dout, "dout"), _lib.dev(dq, "dq"), _lib.dev(dk, "dk"),
-              _lib.dev(dv, "dv"), B, H, L, D, window, ld, ld, ld, H * D, H * D, ld, ld, ld, 1.0 / math.sqrt(D), p, seed,
+              _lib.dev(dv, "dv"), B, H, L, D, window, ld, ld, ld, H * D, H * D, ld, ld, ld, 1.0 / math.sqrt(D), p, seed, _seed_base(),
               _lib.dtype_code(qkv.dtype), _lib.stream_ptr())
         return dqkv, None, None, None, None
 

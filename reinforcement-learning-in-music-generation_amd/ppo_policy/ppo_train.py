@@ -106,6 +106,28 @@ class PPO(object):
             return action[0], logp[0]
         return action, logp
 
+    def _rollout_step_device(self, state_x, reward_mask):
+        with torch.no_grad():
+            action, logp = self.choose_action(state_x)
+            if state_x.shape[0] == 1:
+                action, logp = action.unsqueeze(0), logp.unsqueeze(0)
+            next_state = torch.cat((state_x[:, :N_ACTIONS], action), dim=1)
+            value = self.critic_net.value_produce(next_state)
+            reward = self.eval_net.token_forward(next_state, None, reward_mask)
+        return action, logp, next_state, value, reward
+
+    def rollout_step(self, state_x, reward_mask):
+        """One environment step of the reference's rollout loop (ppo_train.py:475-489) for R rollouts in lock-step:
+        actor greedy action + log-probs, next state = first half of the window + the action rows, critic value of
+        the next state, reward model score.  state_x (R, W, 6) int64, reward_mask (R, W).
+        -> action (R, NA, 6), logp (R, NA, 6), next_state (R, W, 6), value, reward.  The whole step (three
+        network forwards, ~900 launches at W = 50) is replayed as one hipGraph unless CWLT_GRAPHS=0."""
+        if not ops.GRAPHS_ENABLED:
+            return self._rollout_step_device(state_x, reward_mask)
+        if getattr(self, "_graph_step", None) is None:
+            self._graph_step = ops.GraphedCall(self._rollout_step_device)
+        return tuple(o.clone() for o in self._graph_step(state_x, reward_mask.float()))
+
     def select_udpate(self, state_x):
         """ppo_train.py:293-346: the greedy rows / log-probs of the LAST batch element + critic values."""
         net = self.actor_net
@@ -184,13 +206,10 @@ def main():
             Expert_mask_state = train_mask[song, num: num + WINDOW_SIZE]
             Expert_mask_nextstate = train_mask[song, num + 1: num + 1 + WINDOW_SIZE]
             done = torch.tensor(0).long().to(device)
-            action, log_prob_res = Agent.choose_action(state_x.unsqueeze(0))
-            next_state = torch.cat((state_x[:N_ACTIONS, :], action), dim=0)
+            action, log_prob_res, next_state, value_state, agent_reward = (
+                t[0] for t in Agent.rollout_step(state_x.unsqueeze(0), Expert_mask_state.unsqueeze(0)))
+            value_state, agent_reward = value_state.reshape(1, 1), agent_reward.reshape(1, 1)
             state_x = next_state
-            with torch.no_grad():
-                value_state = Agent.critic_net.value_produce(state_x.unsqueeze(0))
-            agent_reward = Agent.eval_net.token_forward(state_x.unsqueeze(0), Expert_state,
-                                                        Expert_mask_state.unsqueeze(0))
             AgentBuffer.store_transition(state_x, action, log_prob_res, value_state, agent_reward, next_state, done)
             ExpertBuffer.store_transition(Expert_state, action, Expert_reward, Expert_next_state, Expert_done,
                                           Expert_mask_state, Expert_mask_nextstate)

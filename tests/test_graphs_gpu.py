@@ -1,0 +1,113 @@
+"""GPU: hipGraph replay of the launch-bound RL rollout steps (ops.GraphedCall) -- same results as the eager
+launches, parameters read in place, fresh dropout masks on every replay through the device-side seed base."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+from fill import fill_params  # noqa: E402
+
+import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import ops  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _small(cfg_dict):
+    old = dict(cfg_dict)
+    cfg_dict.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    return old
+
+
+def test_graphed_dropout_draws_fresh_masks_per_replay(cuda):
+    x = torch.ones(4096, 512, device=cuda)
+    call = ops.GraphedCall(lambda t: ops.posenc_dropout(t, None, 64, 0.5, 1234))
+    a = call(x).clone()
+    b = call(x).clone()
+    c = call(2 * x).clone()
+    for t, scale in ((a, 2.0), (b, 2.0), (c, 4.0)):
+        kept = t != 0
+        assert abs(kept.float().mean().item() - 0.5) < 0.01
+        assert torch.all(t[kept] == scale)
+    assert 0.4 < ((a != 0) ^ (b != 0)).float().mean().item() < 0.6      # independent masks
+    assert 0.4 < ((b != 0) ^ (c != 0)).float().mean().item() < 0.6
+    # eager launches do not use the seed base: same seed -> same mask, before and after replays
+    e1 = ops.posenc_dropout(x, None, 64, 0.5, 1234)
+    call(x)
+    e2 = ops.posenc_dropout(x, None, 64, 0.5, 1234)
+    assert torch.equal(e1, e2)
+
+
+def test_graphed_dqn_choose_action_equals_eager_and_sees_weight_updates(cuda, monkeypatch):
+    from rlmg_amd.dqn_policy import IRL_dqn_train as T, config
+    old = _small(config.AgentConfig)
+    try:
+        n_class = [56, 135, 18, 87, 18, 25]
+        agent = T.DQN(n_class, Pretrain=False)
+        fill_params(agent.eval_net, seed=61)
+        agent.eval_net.eval()
+        g = torch.Generator().manual_seed(1)
+        xs = [torch.stack([torch.randint(0, n, (1, 50), generator=g) for n in n_class], -1).to(cuda) for _ in range(3)]
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", False)
+        eager = [agent.choose_action(x) for x in xs]
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", True)
+        graphed = [agent.choose_action(x) for x in xs]
+        assert all(torch.equal(a, b) for a, b in zip(eager, graphed))
+        assert len(agent._graph_choose.graphs) == 1                       # one capture, three replays
+        with torch.no_grad():                                             # an "optimizer step": in-place update
+            for p in agent.eval_net.parameters():
+                p.mul_(-1.0)
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", False)
+        eager2 = agent.choose_action(xs[0])
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", True)
+        graphed2 = agent.choose_action(xs[0])
+        assert torch.equal(eager2, graphed2) and not torch.equal(eager2, eager[0])
+        # a batch of rollouts is a second signature
+        xb = torch.cat(xs, 0)
+        got = agent.choose_action(xb)
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", False)
+        want = agent.choose_action(xb)
+        assert got.shape == (3, 25, 6) and torch.equal(got, want) and torch.equal(got[0], eager2)
+        assert len(agent._graph_choose.graphs) == 2
+    finally:
+        config.AgentConfig.update(old)
+
+
+def test_graphed_ppo_rollout_step_equals_eager(cuda, monkeypatch):
+    from rlmg_amd.ppo_policy import config, ppo_train as P
+    old_a, old_d = _small(config.ActorConfig), _small(config.DiscriConfig)
+    try:
+        n_token = [49, 19, 19, 89, 67, 25]
+        agent = P.PPO(n_token, Pretrain=False)
+        for i, net in enumerate((agent.actor_net, agent.critic_net, agent.eval_net)):
+            fill_params(net, seed=80 + i)
+            net.eval()
+        g = torch.Generator().manual_seed(2)
+        x = torch.stack([torch.randint(0, n, (2, 50), generator=g) for n in n_token], -1).to(cuda)
+        mask = torch.ones(2, 50, device=cuda)
+        mask[1, 40:] = 0
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", False)
+        eager = agent.rollout_step(x, mask)
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", True)
+        for _ in range(2):
+            graphed = agent.rollout_step(x, mask)
+            for a, b in zip(eager, graphed):
+                assert a.shape == b.shape
+                assert torch.equal(a, b) if a.dtype == torch.int64 else (a - b).abs().max().item() < 1e-6
+        action, logp, nxt, value, reward = graphed
+        assert action.shape == (2, 25, 6) and logp.shape == (2, 25, 6) and nxt.shape == (2, 50, 6)
+        assert torch.equal(nxt[:, :25], x[:, :25]) and torch.equal(nxt[:, 25:], action)
+        assert value.shape == (2, 1) and reward.shape == (2, 1)
+        # train() mode: dropout live, replays differ from each other (seed base advances)
+        for net in (agent.actor_net, agent.critic_net, agent.eval_net):
+            net.train()
+        agent._graph_step = None
+        v1 = agent.rollout_step(x, mask)[3]
+        v2 = agent.rollout_step(x, mask)[3]
+        assert torch.isfinite(v1).all() and not torch.equal(v1, v2)
+    finally:
+        config.ActorConfig.update(old_a)
+        config.DiscriConfig.update(old_d)
