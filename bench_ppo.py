@@ -10,8 +10,9 @@ one rollout to R rollouts per GPU run in lock-step:
       indexing incl. its quirks) -> next state = first half of the old window + the W/2 action tokens ->
       critic value -> reward model (Longformer, band attention) -> GPU-resident buffer write
   update phase, PPO_STEPS inner steps: per rollout, `select_udpate` on its (EPISODES, W, 6) states, ratio-clip
-      surrogate + CE vs the expert windows, critic MSE; gradients accumulated over the R rollouts, one Adam step
-      per net per inner step (data-parallel all-reduce across GPUs when N > 1).
+      surrogate + CE vs the expert windows, critic MSE; gradients accumulated over the R rollouts (--group of
+      them stacked per network pass), one Adam step per net per inner step (data-parallel all-reduce across
+      GPUs when N > 1).
 env-step = one (rollout, step) pair.  Prints one JSON line: whole-iteration and rollout-only
 env-steps/s.  bf16 activations, dropout live (the reference trains with nets in train() mode).
 """
@@ -44,6 +45,7 @@ def main():
     ap.add_argument("--iters", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--group", type=int, default=8, help="rollouts stacked per update pass (1 = one at a time)")
     ap.add_argument("--no-graphs", action="store_true", help="launch the rollout step eagerly (no hipGraph)")
     args = ap.parse_args()
 
@@ -61,6 +63,7 @@ def main():
     gemm_tuning.enable()
     R, W, E = args.rollouts, args.window, args.episodes
     NA = W // 2
+    G = max(1, args.group)
     P.N_ACTIONS = P.NUM_ACTION = NA
     P.N_STATES = P.WINDOW_SIZE = W
     n_token = [49, 19, 19, 89, 67, 25]
@@ -97,21 +100,7 @@ def main():
             rets.append(ret)
             advs.append(adv)
         for _ in range(args.ppo_steps):
-            agent.actor_sync.zero_grad()
-            agent.critic_sync.zero_grad()
-            for r in range(R):                                                  # gradient accumulation over rollouts
-                st = states[:, r]
-                _, new_logp, value_pred = agent.select_udpate(st)
-                pl = rl_ops.ppo_policy_loss(new_logp, old_int[:, r], advs[r], P.PPO_CLIP)
-                ce = agent.actor_net.train_step(st, expert[r, :E + W].unfold(0, W, 1)[:E].permute(0, 2, 1),
-                                                mask[r, :E + W].unfold(0, W, 1)[:E])
-                actor_loss = (pl + (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6) / R
-                actor_loss.backward()
-                (torch.nn.functional.mse_loss(rets[r], value_pred).sum() / R).backward()
-            agent.actor_sync.finish()
-            agent.critic_sync.finish()
-            agent.actor_optim.step()
-            agent.critic_optim.step()
+            agent.update_rollouts(states, old_int, advs, rets, expert, mask, group=G)
         return t_roll
 
     def fence():
@@ -143,7 +132,7 @@ def main():
             "rollout_only_env_steps_per_s": round(steps / t_roll, 2),
             "config": {"workload": "ppo_train iteration: %d rollouts/GPU x window %d, EPISODES %d, PPO_STEPS %d, "
                                    "actor/critic 512/12/8, reward Longformer 512/12/8 w=512" % (R, W, E, args.ppo_steps),
-                       "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
+                       "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "update_group": G, "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
                        "parallelism": "dp%d" % world}}), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -138,6 +138,51 @@ class PPO(object):
         value_state = self.critic_net.value_produce(state_x)
         return action, logp, value_state
 
+    def update_rollouts(self, states, old_logp_int, advs, rets, expert, mask, group=8, clip=None):
+        """One PPO inner step (the body of update_policy's loop, ppo_train.py:360-420) over R rollouts run in
+        lock-step -- the many-rollout generalisation bench_ppo.py measures (BASELINE configs[2]).
+        states (E, R, W, 6) int64, old_logp_int (E, R, NA, 6) int64 (the buffer's `.long()` log-probs),
+        advs / rets: R tensors (E,), expert (R, >= E + W, 6), mask (R, >= E + W).
+        Per rollout, as the reference does for its single one: `select_udpate` on the (E, W, 6) states, the
+        ratio-clip surrogate on the last batch element's rows, the mean of 6 CE losses vs the expert windows,
+        the (E,) vs (E, 1) broadcast MSE for the critic; losses averaged over the R rollouts, one Adam step per
+        net.  `group` rollouts are stacked to (group*E, W, 6) per network pass; summing their losses before one
+        backward equals accumulating their separate backwards."""
+        clip = PPO_CLIP if clip is None else clip
+        E, R, W = states.shape[0], states.shape[1], states.shape[2]
+        NA = old_logp_int.shape[2]
+        dev = states.device
+        actor, critic = self.actor_net, self.critic_net
+        back = torch.arange(NA, device=dev)
+        self.actor_sync.zero_grad()
+        self.critic_sync.zero_grad()
+        for r0 in range(0, R, group):
+            k = min(group, R - r0)
+            st = states[:, r0:r0 + k].transpose(0, 1).reshape(k * E, W, 6)              # rollout-major
+            logits = actor.fused_logits(actor.forward_hidden(st))                         # select_udpate pass
+            value_pred = critic.value_produce(st).view(k, E, 1)
+            rows = (((torch.arange(k, device=dev) + 1) * E - 1) * W + (W - 1))[:, None] - back[None, :]
+            logp_all, _ = rl_ops.logp_argmax(logits.index_select(0, rows.reshape(-1)).float(), self.n_class)
+            logp_all = logp_all.view(k, NA, 6)
+            tgt = expert[r0:r0 + k, :E + W].unfold(1, W, 1)[:, :E].permute(0, 1, 3, 2).reshape(k * E, W, 6)
+            m = mask[r0:r0 + k, :E + W].unfold(1, W, 1)[:, :E].float()                    # (k, E, W)
+            # train_step returns sum(mask * nll) / sum(mask) over its batch; weighting each rollout's mask by
+            # 1 / its own mask sum makes that the mean of the k per-rollout masked means, exactly
+            m = (m / m.sum(dim=(1, 2), keepdim=True)).reshape(k * E, W)
+            ce = actor.train_step(st, tgt, m)                                             # second actor pass
+            actor_loss = (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6 * k
+            critic_loss = 0
+            for j in range(k):
+                actor_loss = actor_loss + rl_ops.ppo_policy_loss(logp_all[j], old_logp_int[:, r0 + j],
+                                                                 advs[r0 + j], clip)
+                critic_loss = critic_loss + torch.nn.functional.mse_loss(rets[r0 + j], value_pred[j]).sum()
+            (actor_loss / R).backward()
+            (critic_loss / R).backward()
+        self.actor_sync.finish()
+        self.critic_sync.finish()
+        self.actor_optim.step()
+        self.critic_optim.step()
+
     def calculate_returns(self, rewards, discount_factor, normalize=True):
         ret, _ = rl_ops.ppo_returns_adv(rewards.to(device), torch.zeros_like(rewards, device=device), discount_factor,
                                         normalize)

@@ -130,3 +130,67 @@ def test_agent_pretrain_train_short_run(cuda, tmp_path, monkeypatch):
         assert any(f.startswith("trainloss_") for f in os.listdir("ckpt"))
     finally:
         config.AgentConfig.update(old)
+
+
+def test_ppo_update_rollouts_grouping_is_exact(cuda, tmp_path, monkeypatch):
+    """Stacking `group` rollouts per network pass gives the gradients of one-rollout-at-a-time accumulation, and
+    those equal the literal per-rollout recipe (select_udpate + policy loss + CE + critic MSE) summed by hand."""
+    monkeypatch.chdir(tmp_path)
+    from rlmg_amd import rl_ops
+    from rlmg_amd.ppo_policy import config, ppo_train as P
+    old_a, old_d = _small(config.ActorConfig), _small(config.DiscriConfig)
+    try:
+        n_token = [49, 19, 19, 89, 67, 25]
+        E, R, W, NA = 4, 3, 50, 25
+        g = torch.Generator().manual_seed(5)
+        states = torch.stack([torch.randint(0, n, (E, R, W), generator=g) for n in n_token], -1).to(cuda)
+        expert = torch.stack([torch.randint(0, n, (R, E + W + 3), generator=g) for n in n_token], -1).to(cuda)
+        mask = torch.ones(R, E + W + 3)
+        mask[1, 40:] = 0                                   # ragged: rollout 1 has a shorter valid span
+        mask = mask.to(cuda)
+        old_int = (-3 * torch.rand(E, R, NA, 6, generator=g)).long().to(cuda)
+        advs = [torch.randn(E, generator=g).to(cuda) for _ in range(R)]
+        rets = [torch.randn(E, generator=g).to(cuda) for _ in range(R)]
+
+        def fresh():
+            torch.manual_seed(0)
+            agent = P.PPO(n_token, Pretrain=False)
+            fill_params(agent.actor_net, seed=71)
+            fill_params(agent.critic_net, seed=72)
+            agent.actor_net.eval()
+            agent.critic_net.eval()
+            for opt in (agent.actor_optim, agent.critic_optim):      # keep the gradients, skip the step
+                monkeypatch.setattr(opt, "step", lambda *a, **k: None)
+            return agent
+
+        def grads(agent):
+            return [p.grad.detach().clone() for net in (agent.actor_net, agent.critic_net) for p in net.parameters()]
+
+        a1 = fresh()
+        a1.update_rollouts(states, old_int, advs, rets, expert, mask, group=1)
+        g1 = grads(a1)
+        a3 = fresh()
+        a3.update_rollouts(states, old_int, advs, rets, expert, mask, group=2)     # groups of 2 + 1
+        g3 = grads(a3)
+        ref = fresh()
+        ref.actor_sync.zero_grad()
+        ref.critic_sync.zero_grad()
+        for r in range(R):
+            st = states[:, r]
+            _, new_logp, value_pred = ref.select_udpate(st)
+            pl = rl_ops.ppo_policy_loss(new_logp, old_int[:, r], advs[r], P.PPO_CLIP)
+            ce = ref.actor_net.train_step(st, expert[r, :E + W].unfold(0, W, 1)[:E].permute(0, 2, 1),
+                                          mask[r, :E + W].unfold(0, W, 1)[:E])
+            ((pl + (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6) / R).backward()
+            (torch.nn.functional.mse_loss(rets[r], value_pred).sum() / R).backward()
+        ref.actor_sync.finish()
+        ref.critic_sync.finish()
+        g0 = grads(ref)
+        scale = max(t.abs().max().item() for t in g0)
+        assert scale > 1e-4
+        for x, y, z in zip(g0, g1, g3):
+            assert (x - y).abs().max().item() < 2e-5 * max(1.0, scale)
+            assert (x - z).abs().max().item() < 2e-5 * max(1.0, scale)
+    finally:
+        config.ActorConfig.update(old_a)
+        config.DiscriConfig.update(old_d)
