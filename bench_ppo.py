@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--group", type=int, default=8, help="rollouts stacked per update pass (1 = one at a time)")
+    ap.add_argument("--tune-gemms", action="store_true", help="extend the GEMM table with this workload's shapes")
     ap.add_argument("--no-graphs", action="store_true", help="launch the rollout step eagerly (no hipGraph)")
     args = ap.parse_args()
 
@@ -60,7 +61,10 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    gemm_tuning.enable()
+    if args.tune_gemms:
+        gemm_tuning.tune(os.path.join(ROOT, "gpurun_out", "gemm_gfx950.csv"))
+    else:
+        gemm_tuning.enable()
     R, W, E = args.rollouts, args.window, args.episodes
     NA = W // 2
     G = max(1, args.group)

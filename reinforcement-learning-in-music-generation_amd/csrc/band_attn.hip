@@ -16,6 +16,7 @@
 // One workgroup = 64 queries of one (b, h); key tiles of 64 inside the band; online softmax; f32 FMA
 // from LDS (the problem is tiny: L = 50..1024, w = 25..256; HBM/latency-bound, not MFMA-shaped).
 #include "cwlt_common.h"
+#include "cwlt_mfma_bf16.h"
 
 namespace cwlt {
 
@@ -171,6 +172,131 @@ __global__ __launch_bounds__(256) void band_attn_fwd_kernel(const T* __restrict_
         store4(ob + (long)i * ldo + 4 * tj, make_float4(o[a][0] * inv, o[a][1] * inv, o[a][2] * inv, o[a][3] * inv));
         // log-sum-exp of the row (for the backward); +inf marks rows whose output is forced to zero
         if (lse && tj == 0) lse[((long)b * H + h) * L + i] = (qok && l_run[a] > 0.f) ? m_run[a] + logf(l_run[a]) : INFINITY;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward, bf16 storage: the same algorithm on v_mfma_f32_32x32x16_bf16 (the f32-FMA kernel above is the
+// parity path and stays the f32 implementation).  Scoring a replay buffer runs this on thousands of
+// 50-token windows per environment step (dqn_policy/AIRL.py:69-91), where the FMA version was the largest
+// single kernel of the loop.  4 waves (wi, wj); as in the scan kernels every product is taken in the
+// orientation that leaves rows on registers and the QUERY index on lanes:
+//   S^T tile (rows j, cols i) = K Q^T  -> the softmax statistics of query i are lane-local (16 registers +
+//   one cross-half shuffle + a 2-wave exchange through LDS);  probabilities are rounded to bf16 once (as HF
+//   does when the model runs in bf16) into ps[i][j];  O^T tile (rows m, cols i) += V^T P^T with V fetched
+//   transposed by ds_read_b64_tr_b16, so rescaling by alpha_i is a per-lane scalar multiply.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void band_attn_fwd_bf16_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const float* __restrict__ mask, bf16_t* __restrict__ out, float* __restrict__ lse, int H, int L, int w, long ldq,
+    long ldk, long ldv, long ldo, float scale, uint32_t thresh, float keep_scale, uint64_t seed,
+    const uint64_t* __restrict__ seed_base) {
+    using namespace b16;
+    __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // q * scale [i][d]; reused as the output tile
+    __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // k [j][d]
+    __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v [j][m]
+    __shared__ __attribute__((aligned(16))) bf16_t ps[C * LD];   // dropout(p) [i][j]
+    __shared__ float pmax[2][C], psum[2][C], kvalid[C];
+    if (seed_base) seed += *seed_base;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wv >> 1, wj = wv & 1;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int bh = blockIdx.y, b = bh / H, h = bh % H;
+    const int q0 = blockIdx.x * C;
+    const bf16_t* qb = q + ((long)b * L) * ldq + h * D;
+    const bf16_t* kb = k + ((long)b * L) * ldk + h * D;
+    const bf16_t* vb = v + ((long)b * L) * ldv + h * D;
+    bf16_t* ob = out + ((long)b * L) * ldo + h * D;
+    const float* mb = mask ? mask + (long)b * L : nullptr;
+    const int srow = tid >> 3, scol = (tid & 7) * 8;
+    const uint4 u4z = make_uint4(0, 0, 0, 0);
+
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = srow + 32 * it;
+        float x[8];
+        unpack8(q0 + row < L ? *reinterpret_cast<const uint4*>(qb + (long)(q0 + row) * ldq + scol) : u4z, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] *= scale;
+        put_row(qs, row, scol, pack8(x));
+    }
+    const int il = 32 * wi + l31;          // this lane's query row inside the tile
+    const int iq = q0 + il;
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 O = zero16();                   // O^T: rows m = 32 wj + acc_row(r, hf), col i = il
+
+    int kt0 = (q0 - w) / C;
+    if (q0 - w < 0) kt0 = 0;
+    int kt1 = (q0 + C - 1 + w) / C;
+    const int ktmax = (L - 1) / C;
+    if (kt1 > ktmax) kt1 = ktmax;
+
+    for (int kt = kt0; kt <= kt1; ++kt) {
+        const int k0 = kt * C;
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = srow + 32 * it;
+            const bool ok = k0 + row < L;
+            put_row(ks, row, scol, ok ? *reinterpret_cast<const uint4*>(kb + (long)(k0 + row) * ldk + scol) : u4z);
+            put_row(vs, row, scol, ok ? *reinterpret_cast<const uint4*>(vb + (long)(k0 + row) * ldv + scol) : u4z);
+        }
+        if (tid < C) kvalid[tid] = (k0 + tid < L && (!mb || mb[k0 + tid] != 0.f)) ? 1.f : 0.f;
+        __syncthreads();
+
+        f32x16 AT = prod_rows(zero16(), ks, 32 * wj + l31, qs, il, 0, 4, hf);
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int jl = 32 * wj + acc_row(r, hf);
+            const int dlt = iq - (k0 + jl);
+            const bool ok = dlt <= w && dlt >= -w && kvalid[jl] != 0.f;
+            AT[r] = ok ? AT[r] : -INFINITY;
+            mx = fmaxf(mx, AT[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        if (hf == 0) pmax[wj][il] = mx;
+        __syncthreads();
+        const float mnew = fmaxf(m_run, fmaxf(pmax[0][il], pmax[1][il]));
+        const float alpha = (m_run == -INFINITY) ? 0.f : __expf(m_run - mnew);
+        float rs = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float p = (AT[r] == -INFINITY) ? 0.f : __expf(AT[r] - mnew);
+            rs += p;
+            if (thresh) {
+                const uint64_t idx = (((uint64_t)bh * L + (uint64_t)iq) * L) + (uint64_t)(k0 + 32 * wj + acc_row(r, hf));
+                p = dropout_keep(seed, idx, thresh) ? p * keep_scale : 0.f;
+            }
+            AT[r] = p;
+        }
+        rs += __shfl_xor(rs, 32, 64);
+        if (hf == 0) psum[wj][il] = rs;
+        put_acc_T(ps, il, 32 * wj, AT, hf, 0, 64, 0.f);
+        __syncthreads();
+        l_run = l_run * alpha + (psum[0][il] + psum[1][il]);
+        m_run = mnew;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[r] *= alpha;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) O = mfma(tfrag8(vs, 16 * s, 32 * wj, lane), row8(ps, il, 16 * s + 8 * hf), O);
+    }
+    const bool qok = iq < L && (!mb || mb[iq] != 0.f);
+    const float inv = (qok && l_run > 0.f) ? 1.0f / l_run : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) O[r] *= inv;
+    __syncthreads();                                   // all waves are past their last read of qs
+    put_acc_T(qs, il, 32 * wj, O, hf, 0, 64, 0.f);     // output tile [i][m], bf16
+    if (lse && wj == 0 && hf == 0 && iq < L)
+        lse[((long)b * H + h) * L + iq] = (qok && l_run > 0.f) ? m_run + logf(l_run) : INFINITY;
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int row = srow + 32 * it;
+        if (q0 + row < L)
+            *reinterpret_cast<uint4*>(ob + (long)(q0 + row) * ldo + scol) = *reinterpret_cast<const uint4*>(qs + row * LD + scol);
     }
 }
 
@@ -407,7 +533,12 @@ int cwlt_band_attn_fwd(const void* q, const void* k, const void* v, const float*
         hipLaunchKernelGGL((band_attn_fwd_kernel<float>), grid, block, 0, st, (const float*)q, (const float*)k,
                            (const float*)v, mask, (float*)out, lse, H, L, window, (long)ldq, (long)ldk, (long)ldv,
                            (long)ldo, scale, th, ks, seed, seed_base);
-    else if (dtype == CWLT_BF16)
+    else if (dtype == CWLT_BF16 && !((ldq | ldk | ldv | ldo) & 7) &&
+             !(((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (uintptr_t)out) & 15))
+        hipLaunchKernelGGL(band_attn_fwd_bf16_kernel, grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
+                           (const bf16_t*)v, mask, (bf16_t*)out, lse, H, L, window, (long)ldq, (long)ldk, (long)ldv,
+                           (long)ldo, scale, th, ks, seed, seed_base);
+    else if (dtype == CWLT_BF16)   // unaligned views: the generic kernel
         hipLaunchKernelGGL((band_attn_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)k,
                            (const bf16_t*)v, mask, (bf16_t*)out, lse, H, L, window, (long)ldq, (long)ldk, (long)ldv,
                            (long)ldo, scale, th, ks, seed, seed_base);

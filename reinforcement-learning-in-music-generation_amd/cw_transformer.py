@@ -10,7 +10,9 @@ reference's state_dict keys exactly:
 
 `compute_dtype` selects the storage type of activations: torch.float32 reproduces the reference's
 arithmetic (parity mode, logits within 1e-4); torch.bfloat16 is the throughput mode (bf16 GEMMs on
-MFMA, f32 scan state / statistics / losses, f32 master weights).
+MFMA, f32 scan state / statistics / losses, f32 master weights).  A freshly built net starts in the mode named by
+the environment variable CWLT_COMPUTE_DTYPE ("f32", the default, or "bf16"), so the drop-in entry points
+(IRL_dqn_train / ppo_train main loops) can be switched to the throughput mode without touching them.
 """
 import math
 
@@ -56,6 +58,16 @@ class PositionalEncoding(nn.Module):
         return ops.PosEncDropoutFn.apply(x, self.pe, p, ops.next_seed() if p > 0 else 0)
 
 
+def default_compute_dtype():
+    import os
+    name = os.environ.get("CWLT_COMPUTE_DTYPE", "f32").lower()
+    if name in ("f32", "fp32", "float32"):
+        return torch.float32
+    if name in ("bf16", "bfloat16"):
+        return torch.bfloat16
+    raise ValueError("CWLT_COMPUTE_DTYPE must be f32 or bf16, got %r" % name)
+
+
 class CWTrunk(nn.Module):
     def __init__(self, n_token, d_model, n_layer, n_head, d_inner=2048, dropout=0.1, is_training=True,
                  emb_sizes=EMB_SIZES):
@@ -65,7 +77,7 @@ class CWTrunk(nn.Module):
         self.dropout, self.d_inner = dropout, d_inner
         self.n_token = list(n_token)
         self.emb_sizes = list(emb_sizes)
-        self.compute_dtype = torch.float32
+        self.compute_dtype = default_compute_dtype()
         for name, n, d in zip(ATTRS, self.n_token, self.emb_sizes):
             setattr(self, "word_emb_" + name, Embeddings(n, d))
         self.pos_emb = PositionalEncoding(d_model, dropout)

@@ -7,7 +7,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .cw_transformer import ATTRS, Embeddings
+from .cw_transformer import ATTRS, Embeddings, default_compute_dtype
 from .longformer import LongformerModel
 
 DISC_EMB_SIZES = (128, 256, 64, 512, 256, 256)      # dqn_policy/AIRL_model.py:57
@@ -28,7 +28,7 @@ class CWLongformerBase(nn.Module):
         self._lf_args = dict(max_position_embeddings=max_seq, hidden_size=d_model, num_hidden_layers=n_layer,
                              num_attention_heads=n_head, intermediate_size=1024, attention_window=attention_window,
                              hidden_dropout_prob=0.1, attention_probs_dropout_prob=0.1)
-        self.compute_dtype = torch.float32
+        self.compute_dtype = default_compute_dtype()
 
     def _build_longformer(self):
         self.longformer = LongformerModel(**self._lf_args)

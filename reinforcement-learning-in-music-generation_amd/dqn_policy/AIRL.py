@@ -67,19 +67,24 @@ class RewardDiscri(nn.Module):
                 self._ckpt_mtime = m
 
     def calculate_reward(self, states, dones, next_states, mask_states, mask_next_states):
-        """AIRL.py:69-91: score the whole buffer in batches of 100; a tail shorter than 100 keeps 1.0."""
+        """AIRL.py:69-91: score the whole buffer in batches of 100 (`all_forward`, which forces train(): dropout
+        live, BatchNorm on batch statistics); a tail shorter than 100 keeps 1.0.
+        The RL loop calls this on 2 x BUFFER_SIZE windows per environment step, so the 100-window batches are not
+        launched one by one (each is ~150 launches on 5 000 tokens): the Longformer body -- per-window
+        arithmetic, nothing crosses windows -- runs over thousands of windows per pass, and only the score
+        classifier, whose BatchNorm couples the windows of a batch, is applied per consecutive group of 100
+        (`LongFormer.score_in_groups`).  Scores are copied to the host once."""
         n = states.shape[0]
-        pred_val = torch.ones((n, 1))
+        bs = self.batch_size
+        full = (n // bs) * bs
         self._maybe_reload()
-        self.disc_model.eval()
-        with torch.no_grad():
-            for idx in range(n // self.batch_size):
-                s, e = idx * self.batch_size, (idx + 1) * self.batch_size
-                score = self.all_forward(states[s:e].long().cuda(), dones[s:e].long().cuda(),
-                                         next_states[s:e].long().cuda(), mask_states[s:e].long().cuda(),
-                                         mask_next_states[s:e].long().cuda())
-                pred_val[s:e] = score.float().cpu()
-        return pred_val
+        pred_dev = torch.ones((n, 1), device="cuda")
+        if full:
+            self.disc_model.train()                      # what all_forward does on every batch (AIRL.py:62)
+            with torch.no_grad():
+                pred_dev[:full] = self.disc_model.score_in_groups(states[:full].long().cuda(),
+                                                                  mask_states[:full].long().cuda(), bs).float()
+        return pred_dev.cpu()
 
     def update_disc(self, agent_episode, expert_episode, train=True):
         """AIRL.py:121-236: optional discriminator training, then the rewards of the agent and expert buffers +

@@ -38,6 +38,21 @@ class LongFormer(CWLongformerBase):
         seq = self._encode(data, masks)
         return self.score_classifier(seq.float().mean(dim=1))
 
+    def score_in_groups(self, data, masks, group, windows_per_pass=2000):
+        """forward() of consecutive batches of `group` windows, (n, window, 6) -> (n, 1), with the Longformer body
+        run over up to `windows_per_pass` windows at a time.  Equal to calling forward() batch by batch: every
+        op before the score classifier acts on one window (or one token) alone; the classifier's BatchNorm1d is
+        what sees a batch, so it is applied -- running statistics included -- per group, in order."""
+        n = data.shape[0]
+        if n % group:
+            raise ValueError("score_in_groups needs a whole number of groups")
+        out = []
+        for s in range(0, n, windows_per_pass - windows_per_pass % group):
+            e = min(n, s + windows_per_pass - windows_per_pass % group)
+            mean = self._encode(data[s:e], masks[s:e]).float().mean(dim=1)
+            out += [self.score_classifier(mean[g0:g0 + group]) for g0 in range(0, e - s, group)]
+        return torch.cat(out, 0)
+
     def token_forward(self, data, target, loss_mask):
         """Mean of the 6 token CE losses of the discriminator's heads (AIRL_model.py:131-170).  compute_CEloss
         there multiplies an already-meaned CE by the mask and divides by its sum, i.e. the plain mean CE."""

@@ -31,10 +31,18 @@ def enable(table=TABLE):
     return bool(ok)
 
 
-def tune(out=TABLE, max_ms=100, iters=50, rotating_mb=1024):
-    """Switch TunableOp to tuning mode; run the workload once afterwards, then call `save()`."""
+def tune(out=TABLE, max_ms=100, iters=50, rotating_mb=1024, preload=TABLE):
+    """Switch TunableOp to tuning mode; run the workload once afterwards, then call `save()`.  Entries of
+    `preload` (the shipped table) are kept, so only shapes it lacks are tuned and `out` holds the union."""
     import torch.cuda.tunable as tunable
     tunable.enable(True)
+    if os.path.exists(out):          # several tuning runs in a row accumulate into `out`
+        preload = out
+    if preload and os.path.exists(preload):
+        try:
+            tunable.read_file(preload)
+        except Exception:
+            pass
     tunable.tuning_enable(True)
     tunable.set_max_tuning_duration(max_ms)
     tunable.set_max_tuning_iterations(iters)

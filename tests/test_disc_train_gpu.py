@@ -167,3 +167,25 @@ def test_update_disc_trains_and_scores(cuda, tmp_path, monkeypatch):
     # running statistics moved on, because scoring runs in train() mode)
     sd = torch.load("./ckpt/disc_IRL.pt")["model_state_dict"]
     assert all(torch.equal(sd[k].to(after[k].device), after[k]) for k, _ in disc.disc_model.named_parameters())
+
+
+def test_score_in_groups_equals_batch_by_batch_forward(cuda):
+    """Grouped scoring (Longformer over many windows, classifier per group of `group`) == forward() per batch,
+    including the BatchNorm running statistics left behind (train mode, dropout probabilities zeroed)."""
+    import copy
+    n_class = [56, 135, 18, 87, 18, 25]
+    net = _small_airl(47, n_class).to(cuda).train()
+    net.longformer.p_hidden = net.longformer.p_attn = 0.0
+    g = torch.Generator().manual_seed(9)
+    x = torch.stack([torch.randint(0, c, (60, 50), generator=g) for c in n_class], -1).to(cuda)
+    mask = torch.ones(60, 50, dtype=torch.long, device=cuda)
+    mask[7, 41:] = 0
+    ref_net = copy.deepcopy(net)
+    with torch.no_grad():
+        want = torch.cat([ref_net(x[s:s + 20], mask[s:s + 20]) for s in range(0, 60, 20)], 0)
+        got = net.score_in_groups(x, mask, 20, windows_per_pass=50)          # passes of 40 + 20 windows
+    assert (got - want).abs().max().item() < 1e-5
+    bn, bn_ref = net.score_classifier[1], ref_net.score_classifier[1]
+    assert (bn.running_mean - bn_ref.running_mean).abs().max().item() < 1e-6
+    assert (bn.running_var - bn_ref.running_var).abs().max().item() < 1e-6
+    assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 3

@@ -97,3 +97,35 @@ def test_airl_repo_dims_matches_oracle(cuda):
     want = odisc.airl_forward(sd, x, mask, 10, 8, 50)
     got = net.to(cuda)(x.to(cuda), mask.to(cuda))
     assert (got.cpu() - want).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("B,L,H,w", [(2, 50, 8, 25), (1, 50, 2, 256), (3, 70, 1, 8), (2, 200, 2, 25), (1, 1, 1, 3),
+                                     (1, 300, 2, 100)])
+def test_band_attention_bf16_mfma_kernel(cuda, B, L, H, w):
+    """bf16 storage runs the MFMA kernel: vs the f64 oracle on the bf16-rounded inputs (tolerance = bf16 rounding
+    of probabilities and output), same log-sum-exp as the f32 kernel, same dropout keep pattern for one seed."""
+    g = torch.Generator().manual_seed(3 * L + w)
+    qkv = torch.randn(B, L, 3, H, 64, generator=g).bfloat16()
+    mask = torch.ones(B, L)
+    if L > 10:
+        mask[0, L - 5:] = 0
+        mask[-1, 2] = 0
+    x = qkv.to(cuda)
+    for m in (mask, None):
+        ref = olf.band_attention(qkv[:, :, 0].double(), qkv[:, :, 1].double(), qkv[:, :, 2].double(), m, w)
+        md = None if m is None else m.to(cuda)
+        got, lse = ops.band_attention(x[:, :, 0], x[:, :, 1], x[:, :, 2], md, w, want_lse=True)
+        assert got.dtype == torch.bfloat16
+        assert (got.float().cpu().double() - ref).abs().max().item() < 2.5e-2
+        xf = x.float()
+        _, lse32 = ops.band_attention(xf[:, :, 0], xf[:, :, 1], xf[:, :, 2], md, w, want_lse=True)
+        fin = torch.isfinite(lse32)
+        assert torch.equal(fin, torch.isfinite(lse))
+        assert (lse[fin] - lse32[fin]).abs().max().item() < 1e-3
+    if L <= 64:
+        probe = torch.zeros(B, L, 3, H, 64, device=cuda)
+        probe[:, :, 2] = torch.eye(64, device=cuda)[:L][None, :, None, :]
+        k32 = ops.band_attention(probe[:, :, 0], probe[:, :, 1], probe[:, :, 2], None, w, 0.3, 77) != 0
+        pb = probe.bfloat16()
+        k16 = ops.band_attention(pb[:, :, 0], pb[:, :, 1], pb[:, :, 2], None, w, 0.3, 77) != 0
+        assert torch.equal(k32, k16)

@@ -9,6 +9,8 @@ import time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 
+os.environ.setdefault("CWLT_COMPUTE_DTYPE", "bf16")   # throughput mode (BASELINE configs: bf16)
+
 import rlmg_amd  # noqa: F401
 from rlmg_amd import gemm_tuning
 from rlmg_amd.dqn_policy import IRL_dqn_train as T
