@@ -82,7 +82,7 @@ class DQN(object):
         self.agent_buffer = AgentMemory()
         self.expert_buffer = ExpertMemory()
         self.sync = rdist.GradSync(self.eval_net.parameters())           # flat grads; RCCL all-reduce if world > 1
-        self.optim = optim.Adam(self.eval_net.parameters(), lr=init_lr)
+        self.optim = ops.graph_adam(self.eval_net.parameters(), lr=init_lr)
         self.scheduler = optim.lr_scheduler.MultiStepLR(self.optim, milestones=[20, 40], gamma=0.1)
         self.target_count = 0
         self.cnt_update = 0
@@ -114,6 +114,24 @@ class DQN(object):
             action = self._choose_action_device(x)
         return action[0] if x.shape[0] == 1 else action
 
+    def _update_device(self, agent_state, agent_next_state, agent_action, agent_reward, agent_done,
+                       expert_next_state, mask_next_states):
+        """Device part of one update (IRL_dqn_train.py:285-345): losses, backward, Adam step."""
+        y = self._fused(self.eval_net, agent_state)
+        with torch.no_grad():        # the reference leaves this under autograd; the target net is never stepped
+            yt = self._fused(self.target_net, agent_next_state)
+        mse = rl_ops.dqn_td_mse(y, yt, agent_action, agent_reward, agent_done, self.n_class, GAMMA)
+        MSEloss = mse.sum() / 6
+        ce = self.eval_net.train_step(agent_state, expert_next_state, mask_next_states)
+        CEloss = (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6
+        alpha = 0.3
+        total_loss = alpha * MSEloss + (1 - alpha) * CEloss
+        self.sync.zero_grad()
+        total_loss.backward()
+        self.sync.finish()
+        self.optim.step()
+        return MSEloss.detach(), CEloss.detach(), total_loss.detach()
+
     def update(self, agent_transition, expert_transition, mask_next_states, update_flag, epoch):
         if self.target_count % Target_update == 0:
             self.target_net.load_state_dict(self.eval_net.state_dict())
@@ -125,20 +143,16 @@ class DQN(object):
         agent_reward = agent_transition["reward"].float().cuda()
         agent_done = agent_transition["done"].long().cuda()
 
-        y = self._fused(self.eval_net, agent_state)
-        with torch.no_grad():        # the reference leaves this under autograd; the target net is never stepped
-            yt = self._fused(self.target_net, agent_next_state)
-        mse = rl_ops.dqn_td_mse(y, yt, agent_action, agent_reward, agent_done, self.n_class, GAMMA)
-        MSEloss = mse.sum() / 6
-        ce = self.eval_net.train_step(agent_state, expert_next_state.long().cuda(), mask_next_states)
-        CEloss = (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6
-        alpha = 0.3
-        total_loss = alpha * MSEloss + (1 - alpha) * CEloss
-
-        self.sync.zero_grad()
-        total_loss.backward()
-        self.sync.finish()
-        self.optim.step()
+        args = (agent_state, agent_next_state, agent_action, agent_reward, agent_done,
+                expert_next_state.long().cuda(), mask_next_states.float().cuda())
+        if ops.train_graphs_enabled():
+            # batch 30 x 50 tokens: ~2 000 small launches per update -- forward, backward and Adam step are
+            # captured once and replayed as one hipGraph (CWLT_GRAPHS=0: eager)
+            if getattr(self, "_graph_update", None) is None:
+                self._graph_update = ops.GraphedCall(self._update_device, grad=True)
+            MSEloss, CEloss, total_loss = self._graph_update(*args)
+        else:
+            MSEloss, CEloss, total_loss = self._update_device(*args)
         self.scheduler.step()
         self.cnt_update += 1
         m, c, t = MSEloss.item(), CEloss.item(), total_loss.item()

@@ -136,18 +136,47 @@ def _seed_base():
     return _lib.dev(seed_base_tensor()) if _USE_SEED_BASE else None
 
 
-GRAPHS_ENABLED = os.environ.get("CWLT_GRAPHS", "1") != "0"     # CWLT_GRAPHS=0: RL rollout steps launch eagerly
+GRAPHS_ENABLED = os.environ.get("CWLT_GRAPHS", "1") != "0"     # CWLT_GRAPHS=0: RL rollout / update steps launch eagerly
+
+
+TRAIN_GRAPHS = os.environ.get("CWLT_TRAIN_GRAPHS", "0") == "1"
+
+
+def train_graphs_enabled():
+    """Whole-training-step graphs (forward + backward + Adam of DQN.update / PPO.update_policy in one launch).
+    OPT-IN (CWLT_TRAIN_GRAPHS=1) and single process only (under data parallelism the gradient all-reduce is
+    launched from autograd hooks and stays eager).  Off by default: 70 consecutive replays of the captured
+    DQN update are clean in isolation (tools/diag_graph_update.py), but inside the full IRL_dqn_train loop --
+    with the replay-buffer scoring's large eager GEMMs interleaved -- a replay raised hipErrorIllegalAddress
+    after ~30 updates; not root-caused yet."""
+    return GRAPHS_ENABLED and TRAIN_GRAPHS and direct_grads()
+
+
+def graph_adam(params, lr, **kw):
+    """torch.optim.Adam as the reference constructs it; when training steps may be captured, `capturable=True`
+    with the learning rate held in a device tensor, so an LR scheduler's updates reach the captured step."""
+    params = list(params)
+    if train_graphs_enabled() and params and params[0].is_cuda:
+        return torch.optim.Adam(params, lr=torch.tensor(float(lr), device=params[0].device), capturable=True, **kw)
+    return torch.optim.Adam(params, lr=lr, **kw)
 
 
 class GraphedCall:
-    """Run `fn(*tensors)` -- a no-grad, sync-free function of device tensors (an RL rollout step: trunk forward +
-    heads + action gather, a few hundred launches for a 50-token window) -- as ONE hipGraph launch.  Captured once
-    per input signature; replays copy the arguments into the graph's static inputs, bump the dropout seed base
-    (a captured op) and launch.  Parameters are read in place, so optimizer steps between replays are seen.
+    """Run `fn(*tensors)` -- a sync-free function of device tensors -- as ONE hipGraph launch.
+
+    grad=False: a no-grad forward (an RL rollout step: trunk forward + heads + action gather, a few hundred launches
+    for a 50-token window).  Warmed up on a side stream, then captured on the first call.
+    grad=True: a whole training step -- forward, backward and optimizer.step() (optimizers built with
+    capturable=True) -- for the launch-bound small-batch updates of the RL loops.  The first `eager_calls` calls
+    run eagerly (they are real steps and create the optimizer state); the next call is captured, then replayed.
+
+    Captured once per input signature; replays copy the arguments into the graph's static inputs, bump the dropout
+    seed base (a captured op) and launch.  Parameters, gradients and optimizer state are used in place.
     Outputs are the graph's static buffers: valid until the next call with the same signature."""
 
-    def __init__(self, fn, warmup=2):
-        self.fn, self.warmup, self.graphs = fn, warmup, {}
+    def __init__(self, fn, warmup=2, grad=False, eager_calls=2):
+        self.fn, self.warmup, self.grad, self.eager_calls = fn, warmup, grad, eager_calls
+        self.graphs, self.calls = {}, {}
 
     def _capture(self, args):
         global _USE_SEED_BASE
@@ -157,15 +186,18 @@ class GraphedCall:
         was_timing = KernelTimer.enabled
         KernelTimer.enabled = False
         _USE_SEED_BASE = True
+        mode = torch.enable_grad if self.grad else torch.no_grad
         try:
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side), torch.no_grad():
-                for _ in range(self.warmup):
-                    self.fn(*static)
-            torch.cuda.current_stream(dev).wait_stream(side)
+            if not self.grad:
+                side = torch.cuda.Stream(device=dev)
+                side.wait_stream(torch.cuda.current_stream(dev))
+                with torch.cuda.stream(side), torch.no_grad():
+                    for _ in range(self.warmup):
+                        self.fn(*static)
+                torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph), torch.no_grad():
+            with torch.cuda.graph(graph), mode():
                 base.add_(_SEED_STEP)
                 out = self.fn(*static)
         finally:
@@ -177,6 +209,10 @@ class GraphedCall:
         key = tuple((tuple(a.shape), a.dtype, a.device.index) for a in args)
         ent = self.graphs.get(key)
         if ent is None:
+            n = self.calls.get(key, 0)
+            if self.grad and n < self.eager_calls:
+                self.calls[key] = n + 1
+                return self.fn(*args)
             ent = self.graphs[key] = self._capture(args)
         graph, static, out = ent
         for s, a in zip(static, args):

@@ -83,8 +83,8 @@ class PPO(object):
         self.expert_buffer = ExpertMemory()
         self.actor_sync = rdist.GradSync(self.actor_net.parameters())     # RCCL all-reduce when world > 1
         self.critic_sync = rdist.GradSync(self.critic_net.parameters())
-        self.actor_optim = optim.Adam(self.actor_net.parameters(), lr=init_lr)
-        self.critic_optim = optim.Adam(self.critic_net.parameters(), lr=init_lr)
+        self.actor_optim = ops.graph_adam(self.actor_net.parameters(), lr=init_lr)
+        self.critic_optim = ops.graph_adam(self.critic_net.parameters(), lr=init_lr)
         self.target_count = self.cnt_update = 0
         self.mse_val = self.ce_val = self.total_val = 0.0
         self.record_for_epoch = 0
@@ -194,6 +194,24 @@ class PPO(object):
             adv = (adv - adv.mean()) / adv.std()
         return adv
 
+    def _ppo_step_device(self, input_state, log_actions, advantages, returns, expert_states, expert_mask):
+        """Device part of one inner step of update_policy (ppo_train.py:360-420)."""
+        new_action, new_log_prob_action, value_pred = self.select_udpate(input_state)
+        policy_loss = rl_ops.ppo_policy_loss(new_log_prob_action, log_actions, advantages, self._ppo_clip)
+        ce = self.actor_net.train_step(input_state, expert_states, expert_mask)
+        ce_loss = (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6
+        actor_loss = policy_loss + ce_loss
+        value_loss = F.mse_loss(returns, value_pred).sum()
+        self.actor_sync.zero_grad()
+        actor_loss.backward()
+        self.actor_sync.finish()
+        self.actor_optim.step()
+        self.critic_sync.zero_grad()
+        value_loss.backward()
+        self.critic_sync.finish()
+        self.critic_optim.step()
+        return actor_loss.detach(), value_loss.detach()
+
     def update_policy(self, ppo_steps, ppo_clip, advantages, returns):
         agent_all = AgentBuffer.get()
         expert_all = ExpertBuffer.get()
@@ -201,26 +219,22 @@ class PPO(object):
         advantages = advantages.to(device).detach()
         returns = returns.to(device).detach()
         total_policy_loss = total_value_loss = 0.0
+        args = (agent_all["states"], log_actions, advantages.float(), returns.float(), expert_all["states"],
+                expert_all["mask_state"].float())
+        self._ppo_clip = ppo_clip
         for epoch in range(ppo_steps):
-            input_state = agent_all["states"]
-            new_action, new_log_prob_action, value_pred = self.select_udpate(input_state)
-            policy_loss = rl_ops.ppo_policy_loss(new_log_prob_action, log_actions, advantages, ppo_clip)
-            ce = self.actor_net.train_step(input_state, expert_all["states"], expert_all["mask_state"])
-            ce_loss = (ce[0] + ce[1] + ce[2] + ce[3] + ce[4] + ce[5]) / 6
-            actor_loss = policy_loss + ce_loss
-            value_loss = F.mse_loss(returns, value_pred).sum()
-            self.actor_sync.zero_grad()
-            actor_loss.backward()
-            self.actor_sync.finish()
-            self.actor_optim.step()
-            total_policy_loss += actor_loss.item()
-            self.critic_sync.zero_grad()
-            value_loss.backward()
-            self.critic_sync.finish()
-            self.critic_optim.step()
-            total_value_loss += value_loss.item()
-            print("Update_PPO:{}/{}| Actor_loss:{:03f}| Critic_loss:{:.03f}".format(epoch, ppo_steps, actor_loss.item(),
-                                                                                 value_loss.item()))
+            if ops.train_graphs_enabled():
+                # 30 x 50-token states: both networks' forward/backward and Adam steps (~4 000 small launches)
+                # are captured once and replayed as one hipGraph per inner step (CWLT_GRAPHS=0: eager)
+                if getattr(self, "_graph_ppo_step", None) is None:
+                    self._graph_ppo_step = ops.GraphedCall(self._ppo_step_device, grad=True)
+                actor_loss, value_loss = self._graph_ppo_step(*args)
+            else:
+                actor_loss, value_loss = self._ppo_step_device(*args)
+            a, c = actor_loss.item(), value_loss.item()
+            total_policy_loss += a
+            total_value_loss += c
+            print("Update_PPO:{}/{}| Actor_loss:{:03f}| Critic_loss:{:.03f}".format(epoch, ppo_steps, a, c))
         return total_policy_loss / ppo_steps
 
 

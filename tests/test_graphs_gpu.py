@@ -22,6 +22,14 @@ def _small(cfg_dict):
     return old
 
 
+def _same_trajectory(p0, p1, name):
+    """Adam turns last-bit gradient differences (capturable vs default code path) of near-zero gradients into
+    steps of up to ~lr, so a handful of elements may sit a few lr apart; everything else must agree closely."""
+    d = (p0 - p1).abs()
+    assert d.max().item() < 5e-3, name
+    assert (d > 1e-4).float().mean().item() < 2e-2, name
+
+
 def test_graphed_dropout_draws_fresh_masks_per_replay(cuda):
     x = torch.ones(4096, 512, device=cuda)
     call = ops.GraphedCall(lambda t: ops.posenc_dropout(t, None, 64, 0.5, 1234))
@@ -108,6 +116,86 @@ def test_graphed_ppo_rollout_step_equals_eager(cuda, monkeypatch):
         v1 = agent.rollout_step(x, mask)[3]
         v2 = agent.rollout_step(x, mask)[3]
         assert torch.isfinite(v1).all() and not torch.equal(v1, v2)
+    finally:
+        config.ActorConfig.update(old_a)
+        config.DiscriConfig.update(old_d)
+
+
+def test_graphed_dqn_update_matches_eager_updates(cuda, tmp_path, monkeypatch):
+    """Whole-step capture (forward + backward + Adam + LR tensor): five updates with the third one captured and the
+    rest replayed follow the same parameter trajectory as five eager updates (dropout off)."""
+    monkeypatch.chdir(tmp_path)
+    from rlmg_amd.dqn_policy import IRL_dqn_train as T, config
+    old = _small(config.AgentConfig)
+    try:
+        n_class = [56, 135, 18, 87, 18, 25]
+        g = torch.Generator().manual_seed(11)
+        B = 6
+        tok = lambda *s: torch.stack([torch.randint(0, n, s, generator=g) for n in n_class], -1).to(cuda)  # noqa: E731
+        batches = [{"state": tok(B, 50), "action": tok(B, 25), "reward": torch.rand(B, 1, generator=g),
+                    "nextstate": tok(B, 50), "done": torch.zeros(B, 1)} for _ in range(5)]
+        m = torch.ones(B, 50, device=cuda)
+
+        def run(graphs):
+            monkeypatch.setattr(ops, "GRAPHS_ENABLED", graphs)
+            monkeypatch.setattr(ops, "TRAIN_GRAPHS", graphs)
+            agent = T.DQN(n_class, Pretrain=False)
+            fill_params(agent.eval_net, seed=61)
+            agent.eval_net.eval()
+            agent.target_net.eval()
+            agent.scheduler = torch.optim.lr_scheduler.MultiStepLR(agent.optim, milestones=[2, 4], gamma=0.5)
+            losses = [agent.update(tr, dict(tr), m, False, 0) for tr in batches]
+            return agent, losses
+
+        eager, l0 = run(False)
+        graphed, l1 = run(True)
+        assert len(graphed._graph_update.graphs) == 1
+        assert isinstance(graphed.optim.param_groups[0]["lr"], torch.Tensor)
+        assert abs(float(graphed.optim.param_groups[0]["lr"]) - eager.optim.param_groups[0]["lr"]) < 1e-9      # f32 tensor
+        for a, b in zip(l0, l1):
+            assert all(abs(x - y) < 2e-4 * max(1.0, abs(x)) for x, y in zip(a, b))
+        for (k, p0), (_, p1) in zip(eager.eval_net.named_parameters(), graphed.eval_net.named_parameters()):
+            _same_trajectory(p0, p1, k)
+    finally:
+        config.AgentConfig.update(old)
+
+
+def test_graphed_ppo_update_policy_matches_eager(cuda, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    from rlmg_amd.ppo_policy import config, ppo_train as P
+    old_a, old_d = _small(config.ActorConfig), _small(config.DiscriConfig)
+    try:
+        n_token = [49, 19, 19, 89, 67, 25]
+        g = torch.Generator().manual_seed(12)
+        E = P.BUFFER_SIZE
+        tok = lambda *s: torch.stack([torch.randint(0, n, s, generator=g) for n in n_token], -1).to(cuda)  # noqa: E731
+        states, exp_states = tok(E, 50), tok(E, 50)
+        logp = -3 * torch.rand(E, 25, 6, generator=g).to(cuda)
+        adv, ret = torch.randn(E, 1, generator=g).to(cuda), torch.randn(E, generator=g).to(cuda)
+
+        def run(graphs):
+            monkeypatch.setattr(ops, "GRAPHS_ENABLED", graphs)
+            monkeypatch.setattr(ops, "TRAIN_GRAPHS", graphs)
+            agent = P.PPO(n_token, Pretrain=False)
+            fill_params(agent.actor_net, seed=71)
+            fill_params(agent.critic_net, seed=72)
+            agent.actor_net.eval()
+            agent.critic_net.eval()
+            P.AgentBuffer, P.ExpertBuffer = P.AgentMemory(), P.ExpertMemory()
+            P.AgentBuffer.states_agent.copy_(states)
+            P.AgentBuffer.log_actions_agent.copy_(logp)
+            P.ExpertBuffer.states_exp.copy_(exp_states)
+            P.ExpertBuffer.mask_state.fill_(1)
+            loss = agent.update_policy(5, P.PPO_CLIP, adv, ret)
+            return agent, loss
+
+        eager, l0 = run(False)
+        graphed, l1 = run(True)
+        assert len(graphed._graph_ppo_step.graphs) == 1
+        assert abs(l0 - l1) < 2e-4 * max(1.0, abs(l0))
+        for net in ("actor_net", "critic_net"):
+            for (k, p0), (_, p1) in zip(getattr(eager, net).named_parameters(), getattr(graphed, net).named_parameters()):
+                _same_trajectory(p0, p1, (net, k))
     finally:
         config.ActorConfig.update(old_a)
         config.DiscriConfig.update(old_d)

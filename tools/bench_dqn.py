@@ -29,11 +29,21 @@ def main():
     marks = []
     orig_update = T.DQN.update
 
+    trace = os.environ.get("CWLT_TRACE") == "1"
+    count = [0]
+
     def timed_update(self, *a, **k):
         torch.cuda.synchronize()
         if not marks:
             marks.append(time.perf_counter())
-        return orig_update(self, *a, **k)
+        if trace:
+            print("update %d start" % count[0], file=sys.stderr, flush=True)
+        out = orig_update(self, *a, **k)
+        if trace:
+            torch.cuda.synchronize()
+            print("update %d ok" % count[0], file=sys.stderr, flush=True)
+        count[0] += 1
+        return out
 
     T.DQN.update = timed_update
     t0 = time.perf_counter()
