@@ -145,10 +145,14 @@ TRAIN_GRAPHS = os.environ.get("CWLT_TRAIN_GRAPHS", "0") == "1"
 def train_graphs_enabled():
     """Whole-training-step graphs (forward + backward + Adam of DQN.update / PPO.update_policy in one launch).
     OPT-IN (CWLT_TRAIN_GRAPHS=1) and single process only (under data parallelism the gradient all-reduce is
-    launched from autograd hooks and stays eager).  Off by default: 70 consecutive replays of the captured
-    DQN update are clean in isolation (tools/diag_graph_update.py), but inside the full IRL_dqn_train loop --
-    with the replay-buffer scoring's large eager GEMMs interleaved -- a replay raised hipErrorIllegalAddress
-    after ~30 updates; not root-caused yet."""
+    launched from autograd hooks and stays eager).  Off by default because of one unresolved interaction
+    (narrowed down with tools/diag_graph_update.py): with bf16 activations, large EAGER bf16 GEMMs
+    run between replays (the replay-buffer scoring of IRL_dqn_train) corrupt the captured step -- NaN losses
+    after a few replays, once hipErrorIllegalAddress.  Not involved: our wgrad kernel, TunableOp, the autograd
+    worker thread, eager allocations as such (NaN-filled eager tensors between replays are harmless), f32
+    mode.  Forward-only graphs are unaffected: bit-exact against eager over 40 replays with the same GEMMs
+    interleaved (tools/diag_graph_fwd.py).  That points at workspace state shared between hipBLASLt's eager
+    GEMMs and the backward-layout GEMMs recorded in the graph."""
     return GRAPHS_ENABLED and TRAIN_GRAPHS and direct_grads()
 
 

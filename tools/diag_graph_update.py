@@ -19,6 +19,8 @@ def say(msg):
 
 
 def main():
+    if os.environ.get("DIAG_NO_WGRAD") == "1":
+        ops.wgrad_supported = lambda a, b: False
     mode = sys.argv[1] if len(sys.argv) > 1 else "untuned"
     if mode == "tuned":
         say("tuned table: %s" % gemm_tuning.enable())
@@ -29,6 +31,21 @@ def main():
     tok = lambda *s: torch.stack([torch.randint(0, c, s, generator=g) for c in n_class], -1).cuda()  # noqa: E731
     B = 30
     m = torch.ones(B, 50).cuda()
+    inter = os.environ.get("DIAG_INTERLEAVE", "")
+    rew = None
+    if inter == "score":
+        from rlmg_amd.dqn_policy.AIRL import RewardDiscri
+        os.makedirs("gpurun_out/diag_run", exist_ok=True)
+        os.chdir("gpurun_out/diag_run")
+        with contextlib.redirect_stdout(io.StringIO()):
+            rew = RewardDiscri(n_class, Pretrain=False)
+        if os.environ.get("DIAG_REW_DTYPE") == "f32":
+            rew.disc_model.compute_dtype = torch.float32
+        elif os.environ.get("DIAG_REW_DTYPE") == "bf16":
+            rew.disc_model.compute_dtype = torch.bfloat16
+        buf_s, buf_m, buf_d = tok(2000, 50), torch.ones(2000, 50).cuda(), torch.zeros(2000, 1).cuda()
+    big_a = torch.randn(100000, 512, device="cuda").bfloat16() if inter == "gemm" else None
+    big_w = torch.randn(1536, 512, device="cuda").bfloat16() if inter == "gemm" else None
     n_upd = int(os.environ.get("DIAG_UPDATES", "8"))
     if os.environ.get("DIAG_NOGC") == "1":
         import gc
@@ -41,6 +58,16 @@ def main():
         torch.cuda.synchronize()
         say("update %d ok %s graphs=%d" % (i, ["%.4f" % v for v in out], len(getattr(agent, "_graph_update").graphs)
                                           if getattr(agent, "_graph_update", None) else 0))
+        if inter == "score":
+            rew.calculate_reward(buf_s, buf_d, buf_s, buf_m, buf_m)
+            rew.calculate_reward(buf_s, buf_d, buf_s, buf_m, buf_m)
+        elif inter == "gemm":
+            for _ in range(20):
+                torch.mm(big_a, big_w.t())
+        elif inter == "alloc":
+            tmp = [torch.full((n,), float("nan"), dtype=torch.bfloat16, device="cuda")
+                   for n in (1 << 8, 1 << 12, 1 << 16, 1 << 19, 1 << 20, 1 << 22, 1 << 24, 1 << 26, 1 << 28) for _ in range(4)]
+            del tmp
         x = tok(1, 50)
         agent.choose_action(x)
         torch.cuda.synchronize()
