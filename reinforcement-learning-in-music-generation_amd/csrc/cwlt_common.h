@@ -22,11 +22,16 @@ constexpr int WAVE = 64;
 
 __device__ __forceinline__ float bf16_to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
 
-// round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries")
-__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    return (bf16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+// round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries").  gfx950 has the
+// conversion in hardware (v_cvt_pk_bf16_f32, two elements per instruction); the software form costs ~7 VALU
+// instructions and an exec-mask branch per element, which made the HBM-bound kernels issue-bound.
+typedef __bf16 hwbf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ uint32_t f32x2_to_bf16x2(float lo, float hi) {
+    hwbf16x2 v;
+    v[0] = (__bf16)lo;
+    v[1] = (__bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
 }
 
 // 4 consecutive elements -> float4 (16-B load for f32, 8-B load for bf16)
@@ -43,8 +48,8 @@ __device__ __forceinline__ float4 load4(const bf16_t* p) {
 __device__ __forceinline__ void store4(float* p, float4 f) { *reinterpret_cast<float4*>(p) = f; }
 __device__ __forceinline__ void store4(bf16_t* p, float4 f) {
     uint2 r;
-    r.x = (uint32_t)f32_to_bf16(f.x) | ((uint32_t)f32_to_bf16(f.y) << 16);
-    r.y = (uint32_t)f32_to_bf16(f.z) | ((uint32_t)f32_to_bf16(f.w) << 16);
+    r.x = f32x2_to_bf16x2(f.x, f.y);
+    r.y = f32x2_to_bf16x2(f.z, f.w);
     *reinterpret_cast<uint2*>(p) = r;
 }
 __device__ __forceinline__ float load1(const float* p) { return *p; }
@@ -70,10 +75,10 @@ __device__ __forceinline__ void store8(float* p, const float (&x)[8]) {
 }
 __device__ __forceinline__ void store8(bf16_t* p, const float (&x)[8]) {
     uint4 r;
-    r.x = (uint32_t)f32_to_bf16(x[0]) | ((uint32_t)f32_to_bf16(x[1]) << 16);
-    r.y = (uint32_t)f32_to_bf16(x[2]) | ((uint32_t)f32_to_bf16(x[3]) << 16);
-    r.z = (uint32_t)f32_to_bf16(x[4]) | ((uint32_t)f32_to_bf16(x[5]) << 16);
-    r.w = (uint32_t)f32_to_bf16(x[6]) | ((uint32_t)f32_to_bf16(x[7]) << 16);
+    r.x = f32x2_to_bf16x2(x[0], x[1]);
+    r.y = f32x2_to_bf16x2(x[2], x[3]);
+    r.z = f32x2_to_bf16x2(x[4], x[5]);
+    r.w = f32x2_to_bf16x2(x[6], x[7]);
     *reinterpret_cast<uint4*>(p) = r;
 }
 

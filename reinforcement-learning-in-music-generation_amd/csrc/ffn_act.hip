@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* __r
     if (bias) loadf<V>(bias + ci * V, b);
     const long per = (rows + gridDim.y - 1) / gridDim.y;
     const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
-#pragma unroll 2
+#pragma unroll 4
     for (long r = r0; r < r1; ++r) {
         const long off = r * F + ci * V;
         float t[V];
@@ -160,7 +160,10 @@ int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_
     if (!h || !g || rows < 0 || F <= 0 || (F & 7) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
     const int vec = dtype == CWLT_BF16 ? 8 : 4;
-    const dim3 grid((F / vec + 255) / 256, cwlt_rowslab_blocks(rows)), block(256);
+    // forward has no per-slab partial sums to reduce afterwards: use finer slabs (more loads in flight)
+    int64_t nslab = (rows + 7) / 8;
+    if (nslab > 4096) nslab = 4096;
+    const dim3 grid((F / vec + 255) / 256, (unsigned)nslab), block(256);
     hipStream_t st = (hipStream_t)stream;
     const uint32_t th = drop_thresh(p);
     const float ks = drop_scale(p);

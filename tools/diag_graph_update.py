@@ -5,7 +5,7 @@ import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ["CWLT_TRAIN_GRAPHS"] = "1"
+os.environ.setdefault("CWLT_TRAIN_GRAPHS", "1")
 os.environ["CWLT_COMPUTE_DTYPE"] = sys.argv[2] if len(sys.argv) > 2 else "bf16"
 import torch
 
