@@ -97,15 +97,14 @@ class _EncoderLayerFn(torch.autograd.Function):
             # single process: write the 16 parameter gradients straight into .grad (flat f32 buckets),
             # one fused convert+store each, instead of .float() + autograd's accumulate
             at = layer.attention
-            for prm, g in ((at.query_projection.weight, dwqkv[:D]), (at.query_projection.bias, dbqkv[:D]),
-                           (at.key_projection.weight, dwqkv[D:2 * D]), (at.key_projection.bias, dbqkv[D:2 * D]),
-                           (at.value_projection.weight, dwqkv[2 * D:]), (at.value_projection.bias, dbqkv[2 * D:]),
-                           (at.out_projection.weight, dwo), (at.out_projection.bias, dbo),
-                           (layer.linear1.weight, dw1), (layer.linear1.bias, db1),
-                           (layer.linear2.weight, dw2), (layer.linear2.bias, db2),
-                           (layer.norm1.weight, dg1), (layer.norm1.bias, dbe1),
-                           (layer.norm2.weight, dg2), (layer.norm2.bias, dbe2)):
-                ops.deliver_grad(prm, g)
+            ops.deliver_grads(((at.query_projection.weight, dwqkv[:D]), (at.query_projection.bias, dbqkv[:D]),
+                               (at.key_projection.weight, dwqkv[D:2 * D]), (at.key_projection.bias, dbqkv[D:2 * D]),
+                               (at.value_projection.weight, dwqkv[2 * D:]), (at.value_projection.bias, dbqkv[2 * D:]),
+                               (at.out_projection.weight, dwo), (at.out_projection.bias, dbo),
+                               (layer.linear1.weight, dw1), (layer.linear1.bias, db1),
+                               (layer.linear2.weight, dw2), (layer.linear2.bias, db2),
+                               (layer.norm1.weight, dg1), (layer.norm1.bias, dbe1),
+                               (layer.norm2.weight, dg2), (layer.norm2.bias, dbe2)))
             return (dx.view(N, L, D),) + (None,) * 20
         dwqkv = dwqkv.float()
         return (dx.view(N, L, D),

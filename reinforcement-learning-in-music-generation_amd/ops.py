@@ -103,6 +103,28 @@ def deliver_grad(p, g):
         p.grad.add_(g)
 
 
+def deliver_grads(pairs):
+    """deliver_grad for a list of (parameter, gradient) pairs with ONE multi-tensor launch per kind (overwrite /
+    accumulate) instead of one small device copy per parameter (16 per encoder layer, ~9 us each)."""
+    fresh_d, fresh_s, acc_d, acc_s = [], [], [], []
+    for p, g in pairs:
+        if not p.requires_grad:
+            continue
+        if p.grad is None:
+            p.grad = g.float().clone() if g.dtype == torch.float32 else g.float()
+        elif getattr(p, "_cwlt_fresh", False):
+            fresh_d.append(p.grad)
+            fresh_s.append(g.view(p.grad.shape))
+            p._cwlt_fresh = False
+        else:
+            acc_d.append(p.grad)
+            acc_s.append(g.view(p.grad.shape) if g.dtype == p.grad.dtype else g.view(p.grad.shape).to(p.grad.dtype))
+    if fresh_d:
+        torch._foreach_copy_(fresh_d, fresh_s)
+    if acc_d:
+        torch._foreach_add_(acc_d, acc_s)
+
+
 _seed_counter = [0]
 
 
