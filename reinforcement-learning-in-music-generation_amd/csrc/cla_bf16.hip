@@ -8,7 +8,8 @@
 // scan compute-bound at ~4x its HBM time.  Here every product is v_mfma_f32_32x32x16_bf16 (16x the
 // rate).  Accuracy is kept at the level of the bf16 output rounding:
 //   * running states (64x64 KV state and the reverse states) accumulate in f32 MFMA accumulators for
-//     the whole sequence and are fed back as operands split hi + lo (two bf16 MFMAs, ~16 mantissa bits);
+//     the whole sequence and are fed back as operands rounded to bf16 (optionally split hi + lo,
+//     CWLT_STATE_LO in cwlt_mfma_bf16.h -- measured to make no difference to the error);
 //   * the intra-chunk score tile is rounded to bf16 once and the SAME rounded tile feeds both the
 //     numerator and the normaliser, so each output row stays an exactly normalised combination;
 //   * forward / dQ outputs leave through an f32 LDS tile and are rounded to bf16 once.
@@ -133,12 +134,10 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
                     bf16x8 hi, lo;
                     acc_frag(S, s, hi, lo);
                     const bf16x8 b = perm8(qs, 32 * wi + l31, 32 * t + 16 * s, hf);
-                    O = mfma(hi, b, O);
-                    O = mfma(lo, b, O);
+                    O = mfma_hl(hi, lo, b, O);
                     if (t == wj) {
                         acc_frag(Sa, s, hi, lo);
-                        Oa = mfma(hi, b, Oa);
-                        Oa = mfma(lo, b, Oa);
+                        Oa = mfma_hl(hi, lo, b, Oa);
                     }
                 }
             }
@@ -311,8 +310,7 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
                 bf16x8 hi, lo;
                 acc_frag(Ta, 0, hi, lo);
                 const bf16x8 b = first_if(hf == 0, dden_i);
-                Q = mfma(hi, b, Q);
-                Q = mfma(lo, b, Q);
+                Q = mfma_hl(hi, lo, b, Q);
             }
             put_acc_T_f32(os, 32 * wi + l31, 32 * wj, Q, hf);
         }
@@ -461,8 +459,7 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
                 bf16x8 hi, lo;
                 acc_frag(RTa, 0, hi, lo);
                 const bf16x8 b = first_if(hf == 0, 1.0f);
-                K = mfma(hi, b, K);
-                K = mfma(lo, b, K);
+                K = mfma_hl(hi, lo, b, K);
             }
             put_acc_T(ok_, 32 * wi + l31, 32 * wj, K, hf, 0, 64, 0.f);
             // dv^T tile (rows m on regs, cols j on lanes) = g^T A + R2^T kf^T

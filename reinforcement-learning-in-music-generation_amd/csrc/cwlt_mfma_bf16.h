@@ -51,6 +51,21 @@ __device__ __forceinline__ bf16x8 tfrag8(const bf16_t* t, int k0, int c0, int la
     const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * LD));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
+// Running states are f32 accumulators for the whole sequence; as MFMA operands they are rounded to bf16.
+// CWLT_STATE_LO=1 additionally feeds the rounding residual (hi + lo, two bf16 MFMAs, ~16 mantissa bits).
+// Measured against the f64 oracle (tools/scan_accuracy.py, L = 1024 and 4096) the residual changes nothing:
+// rms errors 1.65e-4 / 3.1e-5 / 3.1e-5 / 2.3e-4 (out, dq, dk, dv) with it, 1.66e-4 / 3.3e-5 / 3.2e-5 / 2.3e-4
+// without, identical maxima -- the error is set by the single bf16 roundings of the score tile and of the
+// results.  Default 0: 4-6 % faster scans (fewer conversions and MFMAs).
+#ifndef CWLT_STATE_LO
+#define CWLT_STATE_LO 0
+#endif
+constexpr bool STATE_LO = CWLT_STATE_LO != 0;
+__device__ __forceinline__ f32x16 mfma_hl(const bf16x8& hi, const bf16x8& lo, bf16x8 b, f32x16 acc) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(hi, b, acc, 0, 0, 0);
+    if (STATE_LO) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, b, acc, 0, 0, 0);
+    return acc;
+}
 // accumulator registers 8s..8s+7 as an operand fragment, split hi + lo
 __device__ __forceinline__ void acc_frag(const f32x16& S, int s, bf16x8& hi, bf16x8& lo) {
 #pragma unroll
@@ -97,8 +112,7 @@ __device__ __forceinline__ f32x16 prod_accA(f32x16 acc, const f32x16& X0, const 
             bf16x8 hi, lo;
             acc_frag(X, s, hi, lo);
             const bf16x8 b = perm8(b_t, brow, 32 * t + 16 * s, hf);
-            acc = mfma(hi, b, acc);
-            acc = mfma(lo, b, acc);
+            acc = mfma_hl(hi, lo, b, acc);
         }
     }
     return acc;

@@ -58,7 +58,7 @@ def test_cla_causality(cuda):
 
 @pytest.mark.parametrize("N,L,H", [(2, 130, 8), (1, 1, 1), (1, 64, 2), (3, 65, 1), (1, 50, 8), (2, 1024, 2)])
 def test_cla_bf16_io(cuda, N, L, H):
-    """bf16 storage + bf16 MFMA (hi/lo states): compare against the oracle run on the bf16-rounded inputs."""
+    """bf16 storage + bf16 MFMA (f32 running states): compare against the oracle run on the bf16-rounded inputs."""
     q, k, v, g = (t.bfloat16() for t in _rand(N, L, H, seed=11))
     ref_out, ref_dq, ref_dk, ref_dv = ocla.cla_grads(q.double(), k.double(), v.double(), g.double())
     qd, kd, vd = (t.to(cuda).requires_grad_(True) for t in (q, k, v))
