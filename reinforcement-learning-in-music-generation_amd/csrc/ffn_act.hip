@@ -31,6 +31,35 @@ __device__ __forceinline__ void gelu_parts(float x, float& cdf, float& pdf) {
         pdf = 0.39894228040143267794f * expf(-0.5f * x * x);
     }
 }
+// Two elements at a time on the packed-f32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32: one instruction, two lanes of
+// arithmetic); only |x|, v_rcp, v_exp and the sign transfer stay per element.  Same A&S 7.1.26 formula.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
+    f32x2 u;
+    u[0] = fabsf(x[0]);
+    u[1] = fabsf(x[1]);
+    u = u * 0.70710678118654752440f;
+    const f32x2 den = u * 0.3275911f + 1.0f;
+    f32x2 t;
+    t[0] = __builtin_amdgcn_rcpf(den[0]);
+    t[1] = __builtin_amdgcn_rcpf(den[1]);
+    const f32x2 arg = (u * -1.44269504088896340736f) * u;          // -u^2 * log2(e)
+    f32x2 e;
+    e[0] = __builtin_amdgcn_exp2f(arg[0]);
+    e[1] = __builtin_amdgcn_exp2f(arg[1]);
+    f32x2 poly = t * 1.061405429f + -1.453152027f;
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + -0.284496736f;
+    poly = poly * t + 0.254829592f;
+    poly = poly * t;
+    const f32x2 erfa = 1.0f - poly * e;
+    f32x2 sg;
+    sg[0] = copysignf(erfa[0], x[0]);
+    sg[1] = copysignf(erfa[1], x[1]);
+    cdf = sg * 0.5f + 0.5f;
+    pdf = e * 0.39894228040143267794f;
+}
+
 template <bool FAST>
 __device__ __forceinline__ float gelu_f(float x) {
     float cdf, pdf;
@@ -67,10 +96,23 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* __r
         float t[V];
         VecIO<T>::load(h + off, t);
         const uint32_t km = thresh ? dropout_mask<V>(seed, off, thresh) : 0xffffffffu;
+        if (FAST) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            t[j] = gelu_f<FAST>(t[j] + b[j]);
-            t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
+            for (int j = 0; j < V; j += 2) {
+                f32x2 x, cdf, pdf;
+                x[0] = t[j] + b[j];
+                x[1] = t[j + 1] + b[j + 1];
+                gelu_parts2(x, cdf, pdf);
+                const f32x2 y = x * cdf * keep_scale;
+                t[j] = ((km >> j) & 1u) ? y[0] : 0.f;
+                t[j + 1] = ((km >> (j + 1)) & 1u) ? y[1] : 0.f;
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                t[j] = gelu_f<FAST>(t[j] + b[j]);
+                t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
+            }
         }
         VecIO<T>::store(g + off, t);
     }
@@ -100,10 +142,27 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_bwd_kernel(const T* __r
         VecIO<T>::load(dg + off, d);
         VecIO<T>::load(h + off, t);
         const uint32_t km = thresh ? dropout_mask<V>(seed, off, thresh) : 0xffffffffu;
+        if (FAST) {
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-            d[j] = ((km >> j) & 1u) ? d[j] * keep_scale * gelu_grad_f<FAST>(t[j] + b[j]) : 0.f;
-            acc[j] += d[j];
+            for (int j = 0; j < V; j += 2) {
+                f32x2 x, cdf, pdf, dd;
+                x[0] = t[j] + b[j];
+                x[1] = t[j + 1] + b[j + 1];
+                dd[0] = d[j];
+                dd[1] = d[j + 1];
+                gelu_parts2(x, cdf, pdf);
+                const f32x2 y = dd * keep_scale * (x * pdf + cdf);
+                d[j] = ((km >> j) & 1u) ? y[0] : 0.f;
+                d[j + 1] = ((km >> (j + 1)) & 1u) ? y[1] : 0.f;
+                acc[j] += d[j];
+                acc[j + 1] += d[j + 1];
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) {
+                d[j] = ((km >> j) & 1u) ? d[j] * keep_scale * gelu_grad_f<FAST>(t[j] + b[j]) : 0.f;
+                acc[j] += d[j];
+            }
         }
         VecIO<T>::store(dh + off, d);
     }

@@ -33,6 +33,12 @@ def main():
     bias = torch.randn(F, device=dev)
     t = timeit(lambda: ops.gelu_fwd(h, bias, 0.1, 123))
     print("gelu_fwd   %8.1f us  %7.1f GB/s" % (t * 1e3, R * F * 2 * 2 / t / 1e6))
+    t = timeit(lambda: ops.gelu_fwd(h, bias, 0.0, 0))
+    print("gelu_fwd p=0 %6.1f us  %7.1f GB/s" % (t * 1e3, R * F * 2 * 2 / t / 1e6))
+    t = timeit(lambda: ops.posenc_dropout(h, None, 1024, 0.0, 0))
+    print("posenc p=0 (pure copy through VecIO) %6.1f us  %7.1f GB/s" % (t * 1e3, R * F * 2 * 2 / t / 1e6))
+    t = timeit(lambda: ops.posenc_dropout(h, None, 1024, 0.1, 5))
+    print("posenc p=.1 %6.1f us  %7.1f GB/s" % (t * 1e3, R * F * 2 * 2 / t / 1e6))
     t = timeit(lambda: ops.gelu_bwd(dg, h, bias, 0.1, 123))
     print("gelu_bwd   %8.1f us  %7.1f GB/s" % (t * 1e3, R * F * 2 * 3 / t / 1e6))
     x = torch.randn(R, D, device=dev).bfloat16()
