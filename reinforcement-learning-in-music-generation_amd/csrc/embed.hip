@@ -12,6 +12,7 @@
 // slab of token rows, accumulates into an LDS copy of the table slab (plain read-modify-write, no
 // atomics), and writes a partial that a fixed-order tree sums.  HBM-bound.
 #include "cwlt_common.h"
+#include "cwlt_mfma_bf16.h"
 
 #define CWLT_MAX_ATTR 8
 
@@ -102,6 +103,99 @@ __global__ __launch_bounds__(64) void cw_embed_bwd_kernel(const int64_t* __restr
     for (int id = 0; id < nr; ++id) pp[(long)id * wd] = acc[id * 64 + lane];
 }
 
+// bf16 storage: the same scatter-add as a GEMM on the MFMA pipe.  dTable_f (ids x 64 cols) = onehot(tokens_f)^T .
+// dout_f, contracted over the token rows of this workgroup's row split:
+//   A operand: the one-hot rows are GENERATED in registers (lane of id-row m compares 8 token ids with m);
+//   B operand: a 16-row x 64-col tile of dout staged row-major in LDS and fetched transposed
+//              (ds_read_b64_tr_b16), as in the scan / wgrad kernels;
+//   accumulators: up to EB_MT x 2 tiles of 32 x 32 f32 (ids x cols), summed over the split in fixed order.
+// The LDS read-modify-write version above (kept for f32) serialises one dependent LDS round trip per token
+// row per wave; this one is bound by the coalesced read of dout.  One wave per workgroup.
+constexpr int EB_MT = 5;          // id tiles of 32 -> vocabularies up to 160
+constexpr int EB_MAXROWS = 4096;  // token rows per split whose ids fit the LDS id cache
+
+__global__ __launch_bounds__(64, 2) void cw_embed_bwd_mfma_kernel(const int64_t* __restrict__ tokens, EmbedArgs a,
+                                                               const bf16_t* __restrict__ dout,
+                                                               float* __restrict__ part, long rows, long ldd) {
+    using namespace b16;
+    __shared__ __attribute__((aligned(16))) bf16_t ts[16 * LD];     // dout tile [16 token rows][64 cols]
+    __shared__ __attribute__((aligned(16))) int ids[EB_MAXROWS + 16];
+    const int lane = threadIdx.x, l31 = lane & 31, hf = lane >> 5;
+    int f = 0, cb = 0;
+    {
+        int slab = blockIdx.x;
+        for (int t = 0; t < a.n_attr; ++t) {
+            const int ns = a.width[t] >> 6;
+            if (slab < ns) { f = t; cb = slab; break; }
+            slab -= ns;
+        }
+    }
+    const int nr = a.nrows[f], wd = a.width[f];
+    const int nmt = (nr + 31) >> 5;
+    const long per = (rows + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * per, r1 = min(rows, r0 + per);
+    const int n = (int)(r1 - r0);                       // <= EB_MAXROWS (checked by the launcher)
+    const int npad = (n + 15) & ~15;
+    for (int i = lane; i < npad; i += 64)
+        ids[i] = i < n ? clamp_id(tokens[(r0 + i) * a.n_attr + f], nr) : -1;   // -1 matches no id row
+    const bf16_t* dp = dout + a.off[f] + cb * 64;
+    // this lane's slot of the 16 x 64 tile: row lane / 4 (16 rows), 16 columns starting at (lane % 4) * 16
+    const int trow = lane >> 2, tcol = (lane & 3) * 16;
+    const uint4 u4z = make_uint4(0, 0, 0, 0);
+    uint4 p0, p1;
+#define EB_LOAD(k0)                                                                              \
+    {                                                                                            \
+        const bool ok = (k0) + trow < n;                                                         \
+        const bf16_t* src = dp + (r0 + (k0) + trow) * ldd + tcol;                                \
+        p0 = ok ? *reinterpret_cast<const uint4*>(src) : u4z;                                    \
+        p1 = ok ? *reinterpret_cast<const uint4*>(src + 8) : u4z;                                \
+    }
+    f32x16 acc[EB_MT][2];
+#pragma unroll
+    for (int mt = 0; mt < EB_MT; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = zero16();
+    EB_LOAD(0);
+    for (int k0 = 0; k0 < npad; k0 += 16) {
+        *reinterpret_cast<uint4*>(ts + trow * LD + tcol) = p0;
+        *reinterpret_cast<uint4*>(ts + trow * LD + tcol + 8) = p1;
+        if (k0 + 16 < npad) { EB_LOAD(k0 + 16); }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // lgkmcnt(0): the tile and the ids are visible to this (only) wave
+        const int4 ia = *reinterpret_cast<const int4*>(ids + k0 + 8 * hf);
+        const int4 ib = *reinterpret_cast<const int4*>(ids + k0 + 8 * hf + 4);
+        const bf16x8 b0 = tfrag8(ts, 0, 0, lane), b1 = tfrag8(ts, 0, 32, lane);
+        const int id8[8] = {ia.x, ia.y, ia.z, ia.w, ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+        for (int mt = 0; mt < EB_MT; ++mt) {
+            if (mt < nmt) {
+                const int m = 32 * mt + l31;
+                bf16x8 oh;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) oh[j] = (__bf16)(id8[j] == m ? 1.0f : 0.0f);
+                acc[mt][0] = mfma(oh, b0, acc[mt][0]);
+                acc[mt][1] = mfma(oh, b1, acc[mt][1]);
+            }
+        }
+        __builtin_amdgcn_s_waitcnt(0xc07f);   // transposed reads done before the next tile overwrites ts
+    }
+#undef EB_LOAD
+    const float s = a.scale[f];
+    float* pp = part + (long)blockIdx.y * a.total + a.tabofs[f] + cb * 64;
+#pragma unroll
+    for (int mt = 0; mt < EB_MT; ++mt) {
+        if (mt < nmt) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int id = 32 * mt + acc_row(r, hf);
+                if (id < nr) {
+                    pp[(long)id * wd + l31] = acc[mt][0][r] * s;
+                    pp[(long)id * wd + 32 + l31] = acc[mt][1][r] * s;
+                }
+            }
+        }
+    }
+}
+
 static int fill_args(EmbedArgs& a, const void* const* tables, const int* widths, const int* nrows, int n_attr) {
     if (!tables || !widths || !nrows || n_attr <= 0 || n_attr > CWLT_MAX_ATTR) return CWLT_ERR_ARG;
     int off = 0, tot = 0;
@@ -184,6 +278,10 @@ int cwlt_cw_embed_bwd(const int64_t* tokens, const int* widths, const int* nrows
             hipFuncSetAttribute((const void*)cw_embed_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds);
         hipLaunchKernelGGL((cw_embed_bwd_kernel<float>), grid, block, lds, st, tokens, a, (const float*)dout, part,
+                           (long)rows, (long)ldd);
+    } else if (dtype == CWLT_BF16 && maxr <= 32 * EB_MT && (rows + ns - 1) / ns <= EB_MAXROWS && !(ldd & 7) &&
+               !((uintptr_t)dout & 15)) {
+        hipLaunchKernelGGL(cw_embed_bwd_mfma_kernel, grid, block, 0, st, tokens, a, (const bf16_t*)dout, part,
                            (long)rows, (long)ldd);
     } else if (dtype == CWLT_BF16) {
         if (lds > 64 * 1024)

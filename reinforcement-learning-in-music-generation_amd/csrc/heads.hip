@@ -161,6 +161,170 @@ __global__ __launch_bounds__(256) void heads_ce_bwd_kernel(const T* __restrict__
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Tiled variants (the ones the launchers use whenever the row layout allows 16-byte accesses).
+// The wave-per-row kernels above spend a token row on ~12 dependent cross-lane reductions per attribute and
+// read the logits 2 bytes per lane.  Here a workgroup stages 32 rows x ld columns in LDS with 16-byte coalesced
+// loads (row stride odd in words -> the column walks below are bank-conflict free), then ONE THREAD owns one
+// (row, attribute) softmax and walks its n_f columns serially in LDS: no cross-lane traffic at all.  Attributes
+// are assigned to the 8 half-wave slots in order of decreasing vocabulary so both halves of a wave loop alike.
+// Results that are matrices (probs, dlogits) go back through the LDS tile and leave with coalesced stores.
+// ------------------------------------------------------------------------------------------------
+constexpr int HT_ROWS = 32;
+
+struct TileOrder {
+    int attr[CWLT_MAX_ATTR];   // slot -> attribute index (-1: idle slot)
+};
+
+template <typename T>
+__device__ __forceinline__ void heads_tile_load(const T* __restrict__ logits, float* xs, long r0, long rows, long ld,
+                                                int W1) {
+    constexpr int V = VecIO<T>::N;
+    const int nv = (int)(ld / V);
+    for (int i = threadIdx.x; i < HT_ROWS * nv; i += 256) {
+        const int r = i / nv, cv = i - r * nv;
+        float x[V];
+        if (r0 + r < rows) {
+            VecIO<T>::load(logits + (r0 + r) * ld + cv * V, x);
+        } else {
+#pragma unroll
+            for (int j = 0; j < V; ++j) x[j] = 0.f;
+        }
+#pragma unroll
+        for (int j = 0; j < V; ++j) xs[r * W1 + cv * V + j] = x[j];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void heads_fwd_tile_kernel(const T* __restrict__ logits, HeadArgs a, TileOrder ord,
+                                                             const int64_t* __restrict__ target,
+                                                             const float* __restrict__ mask,
+                                                             float* __restrict__ loss_part,
+                                                             int64_t* __restrict__ argmax, float* __restrict__ pmax,
+                                                             float* __restrict__ probs, long rows, long ld, long ldp,
+                                                             int W1, int used) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];   // [HT_ROWS][W1]
+    __shared__ float red[CWLT_MAX_ATTR][HT_ROWS];
+    const int row = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    const int f = ord.attr[slot];
+    const int n = f >= 0 ? a.n[f] : 0, off = f >= 0 ? a.off[f] : 0;
+    float acc = 0.f;
+    const long ntile = (rows + HT_ROWS - 1) / HT_ROWS;
+    for (long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long r0 = t * HT_ROWS, r = r0 + row;
+        __syncthreads();
+        heads_tile_load<T>(logits, xs, r0, rows, ld, W1);
+        __syncthreads();
+        if (f >= 0 && r < rows) {
+            float* x = xs + row * W1 + off;
+            float mx = -INFINITY;
+            for (int j = 0; j < n; ++j) mx = fmaxf(mx, x[j]);
+            float sum = 0.f;
+            for (int j = 0; j < n; ++j) sum += sm_exp<T>(x[j] - mx);
+            if (target) {
+                long tg = target[r * a.n_attr + f];
+                tg = tg < 0 ? 0 : (tg >= n ? n - 1 : tg);
+                acc += (mask ? mask[r] : 1.f) * ((logf(sum) + mx) - x[tg]);
+            }
+            if (argmax || pmax || probs) {
+                // first index of the largest softmax VALUE (softmax then argmax, as the reference does)
+                float best = -1.f;
+                int bi = 0;
+                for (int j = 0; j < n; ++j) {
+                    const float p = sm_exp<T>(x[j] - mx) / sum;
+                    if (probs) x[j] = p;
+                    if (p > best) { best = p; bi = j; }
+                }
+                if (argmax) argmax[r * a.n_attr + f] = bi;
+                if (pmax) pmax[r * a.n_attr + f] = best;
+            }
+        }
+        if (probs) {
+            __syncthreads();
+            for (int i = threadIdx.x; i < HT_ROWS * used; i += 256) {
+                const int rr = i / used, c = i - rr * used;
+                if (r0 + rr < rows) probs[(r0 + rr) * ldp + c] = xs[rr * W1 + c];
+            }
+        }
+    }
+    if (loss_part) {
+        if (f >= 0) red[slot][row] = acc;
+        __syncthreads();
+        if (threadIdx.x < CWLT_MAX_ATTR && ord.attr[threadIdx.x] >= 0) {
+            float sum = 0.f;
+            for (int i = 0; i < HT_ROWS; ++i) sum += red[threadIdx.x][i];
+            loss_part[(long)blockIdx.x * a.n_attr + ord.attr[threadIdx.x]] = sum;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void heads_ce_bwd_tile_kernel(const T* __restrict__ logits, HeadArgs a,
+                                                                TileOrder ord, const int64_t* __restrict__ target,
+                                                                const float* __restrict__ mask,
+                                                                const float* __restrict__ coef,
+                                                                const float* __restrict__ wrf, T* __restrict__ dlogits,
+                                                                long rows, long ld, int W1, int used) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    constexpr int V = VecIO<T>::N;
+    const int row = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    const int f = ord.attr[slot];
+    const int n = f >= 0 ? a.n[f] : 0, off = f >= 0 ? a.off[f] : 0;
+    const int nv = (int)(ld / V);
+    const long ntile = (rows + HT_ROWS - 1) / HT_ROWS;
+    for (long t = blockIdx.x; t < ntile; t += gridDim.x) {
+        const long r0 = t * HT_ROWS, r = r0 + row;
+        __syncthreads();
+        heads_tile_load<T>(logits, xs, r0, rows, ld, W1);
+        __syncthreads();
+        if (f >= 0 && r < rows) {
+            float* x = xs + row * W1 + off;
+            float mx = -INFINITY;
+            for (int j = 0; j < n; ++j) mx = fmaxf(mx, x[j]);
+            float sum = 0.f;
+            for (int j = 0; j < n; ++j) {
+                const float e = sm_exp<T>(x[j] - mx);
+                x[j] = e;
+                sum += e;
+            }
+            long tg = target[r * a.n_attr + f];
+            tg = tg < 0 ? 0 : (tg >= n ? n - 1 : tg);
+            const float w = wrf ? wrf[r * a.n_attr + f] : (mask ? mask[r] : 1.f) * coef[f];
+            const float inv = 1.0f / sum;
+            for (int j = 0; j < n; ++j) x[j] = (x[j] * inv - (j == (int)tg ? 1.f : 0.f)) * w;
+        } else if (f < 0 && slot == CWLT_MAX_ATTR - 1) {
+            // the last (always idle when n_attr < 8) slot clears the padding columns of its row
+            for (int c = used; c < (int)ld; ++c) xs[row * W1 + c] = 0.f;
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < HT_ROWS * nv; i += 256) {
+            const int rr = i / nv, cv = i - rr * nv;
+            if (r0 + rr < rows) {
+                float x[V];
+#pragma unroll
+                for (int j = 0; j < V; ++j) x[j] = xs[rr * W1 + cv * V + j];
+                VecIO<T>::store(dlogits + (r0 + rr) * ld + cv * V, x);
+            }
+        }
+    }
+}
+
+// slot order: attributes by decreasing vocabulary; returns false when the tiled kernels cannot be used
+static bool tile_plan(const HeadArgs& a, int64_t ld, const void* p0, const void* p1, int vec, TileOrder& ord, int& W1,
+                      size_t& lds) {
+    if (a.n_attr >= CWLT_MAX_ATTR) return false;               // the bwd kernel needs one idle slot for the padding
+    if (ld % vec || ((uintptr_t)p0 & 15) || ((uintptr_t)p1 & 15)) return false;
+    W1 = (int)ld | 1;
+    lds = (size_t)HT_ROWS * W1 * sizeof(float);
+    if (lds > 60 * 1024) return false;
+    int idx[CWLT_MAX_ATTR];
+    for (int f = 0; f < a.n_attr; ++f) idx[f] = f;
+    for (int i = 1; i < a.n_attr; ++i)
+        for (int j = i; j > 0 && a.n[idx[j]] > a.n[idx[j - 1]]; --j) { int t = idx[j]; idx[j] = idx[j - 1]; idx[j - 1] = t; }
+    for (int s = 0; s < CWLT_MAX_ATTR; ++s) ord.attr[s] = s < a.n_attr ? idx[s] : -1;
+    return true;
+}
+
 static int fill_heads(HeadArgs& a, const int* n_class, int n_attr) {
     if (!n_class || n_attr <= 0 || n_attr > CWLT_MAX_ATTR) return CWLT_ERR_ARG;
     int off = 0;
@@ -204,10 +368,23 @@ int cwlt_heads_fwd(const void* logits, const int* n_class, int n_attr, const int
     if (probs && ldp < used) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return loss_sum ? (int)hipMemsetAsync(loss_sum, 0, sizeof(float) * n_attr, st) : CWLT_OK;
-    const int nb = cwlt_heads_blocks(rows);
+    int nb = cwlt_heads_blocks(rows);
     const int64_t* tg = loss_sum ? target : nullptr;
     float* lp = loss_sum ? loss_part : nullptr;
-    if (dtype == CWLT_F32)
+    TileOrder ord;
+    int W1 = 0;
+    size_t lds = 0;
+    if ((dtype == CWLT_F32 || dtype == CWLT_BF16) &&
+        tile_plan(a, ld, logits, logits, dtype == CWLT_BF16 ? 8 : 4, ord, W1, lds)) {
+        const int64_t ntile = (rows + HT_ROWS - 1) / HT_ROWS;
+        if (ntile < nb) nb = (int)ntile;
+        if (dtype == CWLT_F32)
+            hipLaunchKernelGGL((heads_fwd_tile_kernel<float>), dim3(nb), dim3(256), lds, st, (const float*)logits, a,
+                               ord, tg, mask, lp, argmax, pmax, probs, (long)rows, (long)ld, (long)ldp, W1, used);
+        else
+            hipLaunchKernelGGL((heads_fwd_tile_kernel<bf16_t>), dim3(nb), dim3(256), lds, st, (const bf16_t*)logits, a,
+                               ord, tg, mask, lp, argmax, pmax, probs, (long)rows, (long)ld, (long)ldp, W1, used);
+    } else if (dtype == CWLT_F32)
         hipLaunchKernelGGL((heads_fwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)logits, a, tg, mask, lp,
                            argmax, pmax, probs, (long)rows, (long)ld, (long)ldp);
     else if (dtype == CWLT_BF16)
@@ -231,7 +408,24 @@ int cwlt_heads_ce_bwd(const void* logits, const int* n_class, int n_attr, const 
     if (!logits || !target || !coef || !dlogits || rows < 0 || ld < used) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = cwlt_heads_blocks(rows);
+    int nb = cwlt_heads_blocks(rows);
+    TileOrder ord;
+    int W1 = 0;
+    size_t lds = 0;
+    if ((dtype == CWLT_F32 || dtype == CWLT_BF16) &&
+        tile_plan(a, ld, logits, dlogits, dtype == CWLT_BF16 ? 8 : 4, ord, W1, lds)) {
+        const int64_t ntile = (rows + HT_ROWS - 1) / HT_ROWS;
+        if (ntile < nb) nb = (int)ntile;
+        if (dtype == CWLT_F32)
+            hipLaunchKernelGGL((heads_ce_bwd_tile_kernel<float>), dim3(nb), dim3(256), lds, st, (const float*)logits, a,
+                               ord, target, mask, coef, (const float*)nullptr, (float*)dlogits, (long)rows, (long)ld,
+                               W1, used);
+        else
+            hipLaunchKernelGGL((heads_ce_bwd_tile_kernel<bf16_t>), dim3(nb), dim3(256), lds, st, (const bf16_t*)logits,
+                               a, ord, target, mask, coef, (const float*)nullptr, (bf16_t*)dlogits, (long)rows,
+                               (long)ld, W1, used);
+        return (int)hipGetLastError();
+    }
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((heads_ce_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)logits, a, target,
                            mask, coef, (const float*)nullptr, (float*)dlogits, (long)rows, (long)ld, (int)ld);
@@ -255,8 +449,25 @@ int cwlt_heads_logp_bwd(const void* logits, const int* n_class, int n_attr, cons
     if (!logits || !target || !g || !dlogits || rows < 0 || ld < used) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
     hipStream_t st = (hipStream_t)stream;
-    const int nb = cwlt_heads_blocks(rows);
-    // the kernel computes (softmax - onehot) * w; the caller passes w = -g through `neg`
+    int nb = cwlt_heads_blocks(rows);
+    // the kernel computes (softmax - onehot) * w; the caller passes w = -g
+    TileOrder ord;
+    int W1 = 0;
+    size_t lds = 0;
+    if ((dtype == CWLT_F32 || dtype == CWLT_BF16) &&
+        tile_plan(a, ld, logits, dlogits, dtype == CWLT_BF16 ? 8 : 4, ord, W1, lds)) {
+        const int64_t ntile = (rows + HT_ROWS - 1) / HT_ROWS;
+        if (ntile < nb) nb = (int)ntile;
+        if (dtype == CWLT_F32)
+            hipLaunchKernelGGL((heads_ce_bwd_tile_kernel<float>), dim3(nb), dim3(256), lds, st, (const float*)logits, a,
+                               ord, target, (const float*)nullptr, (const float*)nullptr, g, (float*)dlogits,
+                               (long)rows, (long)ld, W1, used);
+        else
+            hipLaunchKernelGGL((heads_ce_bwd_tile_kernel<bf16_t>), dim3(nb), dim3(256), lds, st, (const bf16_t*)logits,
+                               a, ord, target, (const float*)nullptr, (const float*)nullptr, g, (bf16_t*)dlogits,
+                               (long)rows, (long)ld, W1, used);
+        return (int)hipGetLastError();
+    }
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((heads_ce_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)logits, a, target,
                            (const float*)nullptr, (const float*)nullptr, g, (float*)dlogits, (long)rows, (long)ld,

@@ -49,6 +49,13 @@ def main():
     s, y, mean, rstd = ops.ln_fwd(x, a, gam, bet, 1e-5, 0.1, 77)
     t = timeit(lambda: ops.ln_bwd(a, None, s, gam, mean, rstd, 0.1, 77))
     print("ln_bwd     %8.1f us  %7.1f GB/s" % (t * 1e3, R * D * 2 * 4 / t / 1e6))
+    widths, nrows = [128, 256, 64, 512, 256, 256], [56, 135, 18, 87, 18, 25]
+    tables = [torch.randn(n, w, device=dev, requires_grad=True) for n, w in zip(nrows, widths)]
+    tokens = torch.stack([torch.randint(0, n, (R,), device=dev) for n in nrows], -1)
+    emb = ops.cw_embed(tokens, tables, torch.bfloat16)
+    dout = torch.randn_like(emb)
+    t = timeit(lambda: torch.autograd.grad(emb, tables, dout, retain_graph=True))
+    print("embed_bwd  %8.1f us  %7.1f GB/s" % (t * 1e3, R * 1472 * 2 / t / 1e6))
     t = timeit(lambda: h.copy_(dg))
     print("torch copy %8.1f us  %7.1f GB/s  (2 streams, reference point)" % (t * 1e3, R * F * 2 * 2 / t / 1e6))
 
