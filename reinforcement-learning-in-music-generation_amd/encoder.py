@@ -90,7 +90,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         dqkv, dbqkv = ops.cla_bwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2], a, zinv, da.view(N, L, H, D // H),
                                   want_colsum=True)
         dqkv2 = dqkv.view(R, 3 * D)
-        dx = torch.addmm(ds1, dqkv2, wqkv)                                 # residual + projection gradient
+        dx = ds1.addmm_(dqkv2, wqkv)                                       # residual + projection gradient, in place
+                                                                           # (out-of-place addmm first copies ds1: 268 MB)
         dwqkv = wgrad(dqkv2, x2)                                           # (3D, D)
         layer = ctx.layer
         if layer is not None and ops.direct_grads():
