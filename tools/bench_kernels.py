@@ -43,12 +43,15 @@ def main():
 
 def bench_wgrad():
     dev = torch.device("cuda:0")
-    M = 65536
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 65536
     for N1, N2 in ((2048, 512), (512, 2048), (512, 512), (1536, 512)):
         a = torch.randn(M, N1, device=dev).bfloat16()
         b = torch.randn(M, N2, device=dev).bfloat16()
         t0 = timeit(lambda: torch.mm(a.t(), b))
         t1 = timeit(lambda: ops.wgrad(a, b))
+        ref = torch.mm(a.float().t(), b.float())
+        err = (ops.wgrad(a, b) - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 1e-3, err
         fl = 2.0 * M * N1 * N2
         print("wgrad %4dx%4d  torch.mm %7.1f us (%6.0f TF)   cwlt %7.1f us (%6.0f TF)" %
               (N1, N2, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9))
