@@ -201,6 +201,16 @@ def main():
         dt = t.item()
     ms_per_step = 1e3 * dt / args.steps
     tokens_per_s = world * B * T * args.steps / dt
+    replica_spread = None
+    if world > 1:
+        # data-parallel sanity (outside the timed region): every rank must hold the same parameters after the
+        # all-reduced steps; spread = max over ranks - min over ranks of a parameter checksum
+        chk = torch.stack([p.detach().double().sum() for p in net.parameters()]).sum().reshape(1)
+        hi, lo = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        replica_spread = float((hi - lo).item())
+        log("replica parameter checksum spread: %.3e" % replica_spread)
 
     if rank == 0:
         s = 2 if args.dtype == "bf16" else 4
@@ -241,7 +251,7 @@ def main():
                        "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
                        "parallelism": "dp%d" % world, "dropout": 0.1, "params": 38982227,
                        "gemm_table": str(tuned)},
-            "final_loss": round(float(loss.item()), 4),
+            "final_loss": round(float(loss.item()), 4), "replica_spread": replica_spread,
             "model_mfma_frac": round(tokens_per_s / world * FLOP_PER_TOKEN / MFMA_BF16_PEAK, 4),
             "roofline": roofline, "kernels": kernels,
         }

@@ -123,17 +123,26 @@ def main():
         log("iteration %d done" % i)
     fence()
     dt = time.perf_counter() - t0
+    replica_spread = None
     if world > 1:
         t = torch.tensor([dt, t_roll], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt, t_roll = t.tolist()
+        # data-parallel sanity: actor and critic replicas must be identical after the all-reduced updates
+        chk = torch.stack([p.detach().double().sum() for n_ in (agent.actor_net, agent.critic_net)
+                           for p in n_.parameters()]).sum().reshape(1)
+        hi, lo = chk.clone(), chk.clone()
+        torch.distributed.all_reduce(hi, op=torch.distributed.ReduceOp.MAX)
+        torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
+        replica_spread = float((hi - lo).item())
+        log("replica parameter checksum spread: %.3e" % replica_spread)
     if rank == 0:
         steps = world * R * E * args.iters
         print(json.dumps({
             "metric": "PPO env-steps/sec", "value": round(steps / dt, 2), "unit": "env-steps/s", "n_gpus": world,
             "steps": args.iters, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.iters, 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "rollout_only_env_steps_per_s": round(steps / t_roll, 2),
+            "rollout_only_env_steps_per_s": round(steps / t_roll, 2), "replica_spread": replica_spread,
             "config": {"workload": "ppo_train iteration: %d rollouts/GPU x window %d, EPISODES %d, PPO_STEPS %d, "
                                    "actor/critic 512/12/8, reward Longformer 512/12/8 w=512" % (R, W, E, args.ppo_steps),
                        "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "update_group": G, "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,

@@ -7,6 +7,12 @@ all-reduce is launched asynchronously the moment its last gradient has been accu
 exchange of layer i overlaps the backward of layers < i; xGMI is point-to-point, so a few large
 buckets (default 32 MiB) beat many small ones.  With world_size == 1 the same flat buffers serve the
 fused gradient-norm clip, and nothing is communicated.
+
+Two ways a gradient arrives: through autograd (post-accumulate hook) or written straight into the bucket by a
+layer backward (`ops.deliver_grads`, which then calls the parameter's `_cwlt_ready` callback).  Either way a
+parameter must report exactly once per backward.  Steps that run SEVERAL backward passes before the
+optimizer step (gradient accumulation, e.g. PPO.update_rollouts) set `defer = True`: nothing is launched from
+the callbacks and `finish()` reduces every bucket once, after the last backward.
 """
 import torch
 import torch.distributed as dist
@@ -37,11 +43,13 @@ class GradSync:
                 cur, cur_n = [], 0
         if cur:
             self._close(cur)
+        self.defer = False
         self._by_param = {}
         for b in self.buckets:
             for p in b.params:
                 self._by_param[p] = b
                 p.register_post_accumulate_grad_hook(self._on_grad)
+                p._cwlt_ready = self._on_grad          # called by ops.deliver_grads after a direct write
 
     def _close(self, params):
         n = sum(p.numel() for p in params)
@@ -58,6 +66,8 @@ class GradSync:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _on_grad(self, p):
+        if self.defer:
+            return
         b = self._by_param[p]
         b.pending -= 1
         if b.pending == 0:
@@ -78,7 +88,7 @@ class GradSync:
     def finish(self):
         """Wait for every bucket (launching those whose parameters never received a gradient)."""
         for b in self.buckets:
-            if b.work is None and b.pending > 0:
+            if b.work is None and (b.pending > 0 or self.defer):
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:

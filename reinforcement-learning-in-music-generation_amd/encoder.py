@@ -94,9 +94,10 @@ class _EncoderLayerFn(torch.autograd.Function):
                                                                            # (out-of-place addmm first copies ds1: 268 MB)
         dwqkv = wgrad(dqkv2, x2)                                           # (3D, D)
         layer = ctx.layer
-        if layer is not None and ops.direct_grads():
-            # single process: write the 16 parameter gradients straight into .grad (flat f32 buckets),
-            # one fused convert+store each, instead of .float() + autograd's accumulate
+        if layer is not None and ops.direct_grads(layer.linear1.weight):
+            # write the 16 parameter gradients straight into .grad (flat f32 buckets) with one multi-tensor
+            # convert+store, instead of .float() + autograd's accumulate; under data parallelism the buckets
+            # (dist.GradSync) are notified per parameter and launch their all-reduce as they complete
             at = layer.attention
             ops.deliver_grads(((at.query_projection.weight, dwqkv[:D]), (at.query_projection.bias, dbqkv[:D]),
                                (at.key_projection.weight, dwqkv[D:2 * D]), (at.key_projection.bias, dbqkv[D:2 * D]),

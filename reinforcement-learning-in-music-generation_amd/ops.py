@@ -82,12 +82,15 @@ def _call(name, *args):
     _lib.check(st, name)
 
 
-def direct_grads():
-    """True when parameter gradients may be written straight into .grad by the layer backward (single
-    process).  Under data parallelism gradients go through autograd so that GradSync's post-accumulate
-    hooks see each parameter exactly once per backward."""
+def direct_grads(param=None):
+    """True when parameter gradients may be written straight into .grad by the layer backward: always in a
+    single process; under data parallelism only for parameters owned by a `dist.GradSync` (it is told through
+    the parameter's `_cwlt_ready` callback) -- with any other gradient hook (e.g. DDP) gradients go through
+    autograd so that the hooks fire."""
     import torch.distributed as dist
-    return not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return True
+    return param is not None and getattr(param, "_cwlt_ready", None) is not None
 
 
 def deliver_grad(p, g):
@@ -123,6 +126,10 @@ def deliver_grads(pairs):
         torch._foreach_copy_(fresh_d, fresh_s)
     if acc_d:
         torch._foreach_add_(acc_d, acc_s)
+    for p, _ in pairs:                       # data parallel: tell the gradient buckets (dist.GradSync)
+        ready = getattr(p, "_cwlt_ready", None)
+        if ready is not None and p.requires_grad:
+            ready(p)
 
 
 _seed_counter = [0]
@@ -175,7 +182,9 @@ def train_graphs_enabled():
     mode.  Forward-only graphs are unaffected: bit-exact against eager over 40 replays with the same GEMMs
     interleaved (tools/diag_graph_fwd.py).  That points at workspace state shared between hipBLASLt's eager
     GEMMs and the backward-layout GEMMs recorded in the graph."""
-    return GRAPHS_ENABLED and TRAIN_GRAPHS and direct_grads()
+    import torch.distributed as dist
+    single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
+    return GRAPHS_ENABLED and TRAIN_GRAPHS and single
 
 
 def graph_adam(params, lr, **kw):

@@ -156,6 +156,8 @@ class PPO(object):
         back = torch.arange(NA, device=dev)
         self.actor_sync.zero_grad()
         self.critic_sync.zero_grad()
+        # several backward passes accumulate into the buckets: reduce across ranks once, in finish()
+        self.actor_sync.defer = self.critic_sync.defer = True
         for r0 in range(0, R, group):
             k = min(group, R - r0)
             st = states[:, r0:r0 + k].transpose(0, 1).reshape(k * E, W, 6)              # rollout-major
@@ -180,6 +182,7 @@ class PPO(object):
             (critic_loss / R).backward()
         self.actor_sync.finish()
         self.critic_sync.finish()
+        self.actor_sync.defer = self.critic_sync.defer = False
         self.actor_optim.step()
         self.critic_optim.step()
 

@@ -40,6 +40,25 @@ def _worker(rank, world, port, out):
     total = sync.clip_grad_norm_(1e9)
     res = {"grads": [p.grad.clone() for p in net.parameters()], "norm": total.item(),
            "unused": [p.grad.clone() for p in unused.parameters()]}
+    # gradient accumulation: two backward passes per step, one deferred reduction in finish()
+    xs = x[rank * 4:(rank + 1) * 4]
+    sync.zero_grad()
+    sync.defer = True
+    (net(xs[:2]).pow(2).sum() / 4).backward()
+    (net(xs[2:]).pow(2).sum() / 4).backward()
+    sync.finish()
+    sync.defer = False
+    res["accum"] = [p.grad.clone() for p in net.parameters()]
+    # direct delivery: gradients written into the buckets by ops.deliver_grads, buckets notified per parameter
+    from rlmg_amd import ops
+    ps = list(net.parameters())
+    gs = torch.autograd.grad(net(xs).pow(2).mean(), ps)
+    sync.zero_grad()
+    assert all(ops.direct_grads(p) for p in ps)
+    ops.deliver_grads(tuple(zip(ps[:3], gs[:3])))       # two calls, as two layers' backward would do
+    ops.deliver_grads(tuple(zip(ps[3:], gs[3:])))
+    sync.finish()
+    res["direct"] = [p.grad.clone() for p in net.parameters()]
     torch.save(res, out % rank)
     dist.barrier()
     dist.destroy_process_group()
@@ -60,6 +79,10 @@ def test_gradsync_world2_matches_single_process(tmp_path):
     for a, b, c in zip(r0["grads"], r1["grads"], ref):
         assert torch.allclose(a, b, atol=0, rtol=0)
         assert torch.allclose(a, c, atol=1e-6)
+    for key in ("accum", "direct"):
+        for a, b, c in zip(r0[key], r1[key], ref):
+            assert torch.allclose(a, b, atol=0, rtol=0), key
+            assert torch.allclose(a, c, atol=1e-6), key
     assert all(t.abs().sum().item() == 0 for t in r0["unused"])
     ref_norm = torch.linalg.vector_norm(torch.cat([t.flatten() for t in ref])).item()
     assert abs(r0["norm"] - ref_norm) < 1e-5 and abs(r1["norm"] - ref_norm) < 1e-5
