@@ -173,9 +173,11 @@ __device__ __forceinline__ uint4 stage_g(uint4 rdo, uint4 ro, float z, float& dd
         dot = fmaf(a[j], b[j], dot);
         a[j] *= z;
     }
-    dot += __shfl_xor(dot, 1, 64);
-    dot += __shfl_xor(dot, 2, 64);
-    dot += __shfl_xor(dot, 4, 64);
+    // sum over the 8 lanes that share a row: DPP moves (quad xor 1, xor 2, half-row mirror) instead of three
+    // ds_bpermute round trips through the LDS pipe
+    dot += dpp_move<0xB1>(dot);
+    dot += dpp_move<0x4E>(dot);
+    dot += dpp_move<0x141>(dot);
     dden = -dot * z;
     return pack8(a);
 }
