@@ -187,9 +187,17 @@ def main():
                 log("tuned table written")
     fence()
     log("warm-up done, timing %d steps" % args.steps)
-    ops.KernelTimer.reset(rank == 0 and not args.no_kernel_timer)
+    # A pair of HIP timing events around every C-ABI call (~190 calls per step) makes the GPU drain between kernels:
+    # measured +25 ms on a 106 ms step.  The per-kernel durations therefore come from every 10th timed step only
+    # (step 0 of the default 10): still live, inside the timed region, on the launch stream; cost ~2 % of `value`.
+    timing = rank == 0 and not args.no_kernel_timer
+    ops.KernelTimer.reset(False)
+    if timing:
+        ops.KernelTimer.reserve(512 * len([i for i in range(args.steps) if i % 10 == 0]))
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for i in range(args.steps):
+        ops.KernelTimer.enabled = timing and i % 10 == 0
         loss = step()
     fence()
     dt = time.perf_counter() - t0
@@ -218,12 +226,13 @@ def main():
         roofline = None
         kernels = {}
         if kt:
+            n_sampled = len([i for i in range(args.steps) if i % 10 == 0])     # steps on which events were recorded
             tot = {k: c * m for k, (c, m) in kt.items()}
             for k, (c, m) in sorted(kt.items(), key=lambda kv: -tot[kv[0]]):
                 ab = algorithmic_bytes(k, B, T, s=s)
                 fl = algorithmic_flops(k, B, T)
-                kernels[k] = {"calls_per_step": c / args.steps, "avg_ms": round(m, 4),
-                              "share_of_step": round(tot[k] / (dt * 1e3), 4),
+                kernels[k] = {"calls_per_step": c / n_sampled, "avg_ms": round(m, 4),
+                              "share_of_step": round(tot[k] / n_sampled / ms_per_step, 4),
                               "GB/s": round(ab / (m * 1e-3) / 1e9, 1) if ab else None}
                 if fl:
                     kernels[k]["TFLOP/s"] = round(fl / (m * 1e-3) / 1e12, 1)

@@ -53,11 +53,25 @@ class KernelTimer:
     `summary()` (after a device sync) -> {entry point: (calls, mean ms)}."""
     enabled = False
     records = {}
+    pool = []
 
     @classmethod
     def reset(cls, enabled):
         cls.enabled = bool(enabled)
         cls.records = {}
+
+    @classmethod
+    def reserve(cls, n):
+        """Create (and once record) n timing events ahead of the timed region: hipEventCreate is slow, and the
+        first few hundred creations are the slowest."""
+        while len(cls.pool) < n:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            cls.pool.append(e)
+
+    @classmethod
+    def event(cls):
+        return cls.pool.pop() if cls.pool else torch.cuda.Event(enable_timing=True)
 
     @classmethod
     def summary(cls):
@@ -72,7 +86,7 @@ def _call(name, *args):
     """Invoke one libcwlt entry point on the current stream and raise on a non-zero status."""
     fn = getattr(_lib.load(), name)
     if KernelTimer.enabled:
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a, b = KernelTimer.event(), KernelTimer.event()
         a.record()
         st = fn(*args)
         b.record()
