@@ -211,13 +211,12 @@ __global__ __launch_bounds__(256) void band_attn_fwd_bf16_kernel(
     bf16_t* ob = out + ((long)b * L) * ldo + h * D;
     const float* mb = mask ? mask + (long)b * L : nullptr;
     const int srow = tid >> 3, scol = (tid & 7) * 8;
-    const uint4 u4z = make_uint4(0, 0, 0, 0);
 
 #pragma unroll
     for (int it = 0; it < 2; ++it) {
         const int row = srow + 32 * it;
         float x[8];
-        unpack8(q0 + row < L ? *reinterpret_cast<const uint4*>(qb + (long)(q0 + row) * ldq + scol) : u4z, x);
+        unpack8(q0 + row < L ? *reinterpret_cast<const uint4*>(qb + (long)(q0 + row) * ldq + scol) : CWLT_U4Z, x);
 #pragma unroll
         for (int j = 0; j < 8; ++j) x[j] *= scale;
         put_row(qs, row, scol, pack8(x));
@@ -240,8 +239,8 @@ __global__ __launch_bounds__(256) void band_attn_fwd_bf16_kernel(
         for (int it = 0; it < 2; ++it) {
             const int row = srow + 32 * it;
             const bool ok = k0 + row < L;
-            put_row(ks, row, scol, ok ? *reinterpret_cast<const uint4*>(kb + (long)(k0 + row) * ldk + scol) : u4z);
-            put_row(vs, row, scol, ok ? *reinterpret_cast<const uint4*>(vb + (long)(k0 + row) * ldv + scol) : u4z);
+            put_row(ks, row, scol, ok ? *reinterpret_cast<const uint4*>(kb + (long)(k0 + row) * ldk + scol) : CWLT_U4Z);
+            put_row(vs, row, scol, ok ? *reinterpret_cast<const uint4*>(vb + (long)(k0 + row) * ldv + scol) : CWLT_U4Z);
         }
         if (tid < C) kvalid[tid] = (k0 + tid < L && (!mb || mb[k0 + tid] != 0.f)) ? 1.f : 0.f;
         __syncthreads();

@@ -59,7 +59,6 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
-    const uint4 u4z = make_uint4(0, 0, 0, 0);
     uint4 rq[2], rk[2], rv[2];
     const bf16x8 ones0 = ones_if(l31 == 0);   // A operand: row 0 of the ones block, all k
 
@@ -67,9 +66,9 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
         const long row = (long)(c) * C + srow + 32 * it;                                 \
         const bool ok = row < L;                                                         \
-        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : u4z;      \
-        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : u4z;      \
-        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : u4z;      \
+        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : CWLT_U4Z;      \
+        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : CWLT_U4Z;      \
+        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : CWLT_U4Z;      \
     }
 #define CLA_STORE(c)                                                                     \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
@@ -231,7 +230,6 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
-    const uint4 u4z = make_uint4(0, 0, 0, 0);
     uint4 rq[2], rk[2], rv[2], rg[2], ro[2], rqp[2];
     float rz[2];
 
@@ -239,11 +237,11 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
         const long row = (long)(c) * C + srow + 32 * it;                                 \
         const bool ok = row < L;                                                         \
-        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : u4z;      \
-        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : u4z;      \
-        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : u4z;      \
-        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : u4z;     \
-        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : u4z;      \
+        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : CWLT_U4Z;      \
+        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : CWLT_U4Z;      \
+        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : CWLT_U4Z;      \
+        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : CWLT_U4Z;     \
+        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : CWLT_U4Z;      \
         rz[it] = ok ? zb[row * H] : 0.f;                                                 \
     }
 #define CLA_STORE(c)                                                                     \
@@ -370,7 +368,6 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
-    const uint4 u4z = make_uint4(0, 0, 0, 0);
     uint4 rq[2], rk[2], rv[2], rg[2], ro[2];
     float rz[2];
 
@@ -378,11 +375,11 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
         const long row = (long)(c) * C + srow + 32 * it;                                 \
         const bool ok = row < L;                                                         \
-        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : u4z;      \
-        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : u4z;      \
-        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : u4z;      \
-        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : u4z;     \
-        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : u4z;      \
+        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : CWLT_U4Z;      \
+        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : CWLT_U4Z;      \
+        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : CWLT_U4Z;      \
+        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : CWLT_U4Z;     \
+        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : CWLT_U4Z;      \
         rz[it] = ok ? zb[row * H] : 0.f;                                                 \
     }
     // store slot (row, scol): each thread reads exactly the ks slot it re-stages next, so no barrier is needed

@@ -20,6 +20,10 @@ namespace cwlt {
 
 constexpr int WAVE = 64;
 
+// zero 16-byte vector written as a literal at every use: a NAMED constant that stays live across a kernel was
+// being parked in scratch memory by the register allocator and fetched back with scratch_load at each guarded load
+#define CWLT_U4Z make_uint4(0u, 0u, 0u, 0u)
+
 __device__ __forceinline__ float bf16_to_f32(bf16_t x) { return __uint_as_float(((uint32_t)x) << 16); }
 
 // round-to-nearest-even; NaN stays NaN (MI355X_MICROARCH.md "Correctness boundaries").  gfx950 has the

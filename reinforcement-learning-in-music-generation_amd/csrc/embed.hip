@@ -141,14 +141,13 @@ __global__ __launch_bounds__(64, 2) void cw_embed_bwd_mfma_kernel(const int64_t*
     const bf16_t* dp = dout + a.off[f] + cb * 64;
     // this lane's slot of the 16 x 64 tile: row lane / 4 (16 rows), 16 columns starting at (lane % 4) * 16
     const int trow = lane >> 2, tcol = (lane & 3) * 16;
-    const uint4 u4z = make_uint4(0, 0, 0, 0);
     uint4 p0, p1;
 #define EB_LOAD(k0)                                                                              \
     {                                                                                            \
         const bool ok = (k0) + trow < n;                                                         \
         const bf16_t* src = dp + (r0 + (k0) + trow) * ldd + tcol;                                \
-        p0 = ok ? *reinterpret_cast<const uint4*>(src) : u4z;                                    \
-        p1 = ok ? *reinterpret_cast<const uint4*>(src + 8) : u4z;                                \
+        p0 = ok ? *reinterpret_cast<const uint4*>(src) : CWLT_U4Z;                                    \
+        p1 = ok ? *reinterpret_cast<const uint4*>(src + 8) : CWLT_U4Z;                                \
     }
     f32x16 acc[EB_MT][2];
 #pragma unroll

@@ -19,6 +19,9 @@ def say(msg):
 
 
 def main():
+    if os.environ.get("DIAG_BLAS"):
+        torch.backends.cuda.preferred_blas_library(os.environ["DIAG_BLAS"])
+        say("preferred blas: %s" % torch.backends.cuda.preferred_blas_library())
     if os.environ.get("DIAG_NO_WGRAD") == "1":
         ops.wgrad_supported = lambda a, b: False
     mode = sys.argv[1] if len(sys.argv) > 1 else "untuned"
