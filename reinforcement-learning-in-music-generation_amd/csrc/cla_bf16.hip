@@ -62,13 +62,16 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
     uint4 rq[2], rk[2], rv[2];
     const bf16x8 ones0 = ones_if(l31 == 0);   // A operand: row 0 of the ones block, all k
 
+    // this stream's q / k / v rows as buffer resources: rows >= L read back as zeros (hardware range check)
+    const __amdgpu_buffer_rsrc_t qr = make_rsrc(qb, (uint32_t)(((long)(L - 1) * ldq + D) * 2));
+    const __amdgpu_buffer_rsrc_t kr = make_rsrc(kb, (uint32_t)(((long)(L - 1) * ldk + D) * 2));
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(vb, (uint32_t)(((long)(L - 1) * ldv + D) * 2));
 #define CLA_LOAD(c)                                                                      \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
-        const long row = (long)(c) * C + srow + 32 * it;                                 \
-        const bool ok = row < L;                                                         \
-        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : CWLT_U4Z;      \
-        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : CWLT_U4Z;      \
-        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : CWLT_U4Z;      \
+        const uint32_t row = (uint32_t)(c) * C + srow + 32 * it;                         \
+        rq[it] = buf_load16(qr, (row * (uint32_t)ldq + scol) * 2);                       \
+        rk[it] = buf_load16(kr, (row * (uint32_t)ldk + scol) * 2);                       \
+        rv[it] = buf_load16(vr, (row * (uint32_t)ldv + scol) * 2);                       \
     }
 #define CLA_STORE(c)                                                                     \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
@@ -233,16 +236,22 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     uint4 rq[2], rk[2], rv[2], rg[2], ro[2], rqp[2];
     float rz[2];
 
+    // this stream's rows as buffer resources: rows >= L read back as zeros (hardware range check, no branches)
+    const __amdgpu_buffer_rsrc_t qr = make_rsrc(qb, (uint32_t)(((long)(L - 1) * ldq + D) * 2));
+    const __amdgpu_buffer_rsrc_t kr = make_rsrc(kb, (uint32_t)(((long)(L - 1) * ldk + D) * 2));
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(vb, (uint32_t)(((long)(L - 1) * ldv + D) * 2));
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(gb, (uint32_t)(((long)(L - 1) * lddo + D) * 2));
+    const __amdgpu_buffer_rsrc_t orr = make_rsrc(ob, (uint32_t)(((long)(L - 1) * ldo + D) * 2));
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(zb, (uint32_t)(((long)(L - 1) * H + 1) * 4));
 #define CLA_LOAD(c)                                                                      \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
-        const long row = (long)(c) * C + srow + 32 * it;                                 \
-        const bool ok = row < L;                                                         \
-        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : CWLT_U4Z;      \
-        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : CWLT_U4Z;      \
-        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : CWLT_U4Z;      \
-        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : CWLT_U4Z;     \
-        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : CWLT_U4Z;      \
-        rz[it] = ok ? zb[row * H] : 0.f;                                                 \
+        const uint32_t row = (uint32_t)(c) * C + srow + 32 * it;                         \
+        rq[it] = buf_load16(qr, (row * (uint32_t)ldq + scol) * 2);                       \
+        rk[it] = buf_load16(kr, (row * (uint32_t)ldk + scol) * 2);                       \
+        rv[it] = buf_load16(vr, (row * (uint32_t)ldv + scol) * 2);                       \
+        rg[it] = buf_load16(gr, (row * (uint32_t)lddo + scol) * 2);                      \
+        ro[it] = buf_load16(orr, (row * (uint32_t)ldo + scol) * 2);                      \
+        rz[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, (int)(row * (uint32_t)H * 4), 0, 0)); \
     }
 #define CLA_STORE(c)                                                                     \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
@@ -371,16 +380,22 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     uint4 rq[2], rk[2], rv[2], rg[2], ro[2];
     float rz[2];
 
+    // this stream's rows as buffer resources: rows >= L read back as zeros (hardware range check, no branches)
+    const __amdgpu_buffer_rsrc_t qr = make_rsrc(qb, (uint32_t)(((long)(L - 1) * ldq + D) * 2));
+    const __amdgpu_buffer_rsrc_t kr = make_rsrc(kb, (uint32_t)(((long)(L - 1) * ldk + D) * 2));
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(vb, (uint32_t)(((long)(L - 1) * ldv + D) * 2));
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(gb, (uint32_t)(((long)(L - 1) * lddo + D) * 2));
+    const __amdgpu_buffer_rsrc_t orr = make_rsrc(ob, (uint32_t)(((long)(L - 1) * ldo + D) * 2));
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(zb, (uint32_t)(((long)(L - 1) * H + 1) * 4));
 #define CLA_LOAD(c)                                                                      \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
-        const long row = (long)(c) * C + srow + 32 * it;                                 \
-        const bool ok = row < L;                                                         \
-        rq[it] = ok ? *reinterpret_cast<const uint4*>(qb + row * ldq + scol) : CWLT_U4Z;      \
-        rk[it] = ok ? *reinterpret_cast<const uint4*>(kb + row * ldk + scol) : CWLT_U4Z;      \
-        rv[it] = ok ? *reinterpret_cast<const uint4*>(vb + row * ldv + scol) : CWLT_U4Z;      \
-        rg[it] = ok ? *reinterpret_cast<const uint4*>(gb + row * lddo + scol) : CWLT_U4Z;     \
-        ro[it] = ok ? *reinterpret_cast<const uint4*>(ob + row * ldo + scol) : CWLT_U4Z;      \
-        rz[it] = ok ? zb[row * H] : 0.f;                                                 \
+        const uint32_t row = (uint32_t)(c) * C + srow + 32 * it;                         \
+        rq[it] = buf_load16(qr, (row * (uint32_t)ldq + scol) * 2);                       \
+        rk[it] = buf_load16(kr, (row * (uint32_t)ldk + scol) * 2);                       \
+        rv[it] = buf_load16(vr, (row * (uint32_t)ldv + scol) * 2);                       \
+        rg[it] = buf_load16(gr, (row * (uint32_t)lddo + scol) * 2);                      \
+        ro[it] = buf_load16(orr, (row * (uint32_t)ldo + scol) * 2);                      \
+        rz[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, (int)(row * (uint32_t)H * 4), 0, 0)); \
     }
     // store slot (row, scol): each thread reads exactly the ks slot it re-stages next, so no barrier is needed
 #define CLA_STORE(c)                                                                     \

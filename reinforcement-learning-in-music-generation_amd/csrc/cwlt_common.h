@@ -20,6 +20,18 @@ namespace cwlt {
 
 constexpr int WAVE = 64;
 
+// Buffer (SRD) loads: the hardware range check returns zeros for offsets at or past `bytes`, so row guards cost no
+// exec-mask branch, and addressing is one 32-bit byte offset per lane instead of a 64-bit pointer.  Build the
+// descriptor from wave-uniform values only (kernel arguments, blockIdx) so it lives in SGPRs.
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ uint4 buf_load16(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
+
 // zero 16-byte vector written as a literal at every use: a NAMED constant that stays live across a kernel was
 // being parked in scratch memory by the register allocator and fetched back with scratch_load at each guarded load
 #define CWLT_U4Z make_uint4(0u, 0u, 0u, 0u)
