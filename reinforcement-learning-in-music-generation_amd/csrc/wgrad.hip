@@ -61,15 +61,18 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     const bf16_t* Bb = B + (long)t2 * TN;
 
     const int srow = tid >> 5, scol = (tid & 31) * 8;   // one 16-B slot of the 32 x 256 stage per thread
-    const uint4 u4z = make_uint4(0, 0, 0, 0);
     uint4 ra0, rb0, ra1, rb1;   // two register stages: global loads run two steps ahead
 
+    // the slice's rows [m0, m1) of both operands as buffer resources: rows past the slice end read back as zeros
+    // (hardware range check), offsets are 32-bit and relative to the slice start
+    const long nrow = m1 > m0 ? m1 - m0 : 0;
+    const __amdgpu_buffer_rsrc_t ar = make_rsrc(Ab + m0 * lda, nrow ? (uint32_t)(((nrow - 1) * lda + TM) * 2) : 0u);
+    const __amdgpu_buffer_rsrc_t br = make_rsrc(Bb + m0 * ldb, nrow ? (uint32_t)(((nrow - 1) * ldb + TN) * 2) : 0u);
 #define WG_LOAD(RA, RB, ms)                                                                \
     {                                                                                      \
-        const long row = (ms) + srow;                                                      \
-        const bool ok = row < m1;                                                          \
-        RA = ok ? *reinterpret_cast<const uint4*>(Ab + row * lda + scol) : u4z;            \
-        RB = ok ? *reinterpret_cast<const uint4*>(Bb + row * ldb + scol) : u4z;            \
+        const uint32_t row = (uint32_t)((ms) - m0) + srow;                                 \
+        RA = buf_load16(ar, (row * (uint32_t)lda + scol) * 2);                             \
+        RB = buf_load16(br, (row * (uint32_t)ldb + scol) * 2);                             \
     }
 #define WG_STAGE(RA, RB, buf)                                                              \
     {                                                                                      \
