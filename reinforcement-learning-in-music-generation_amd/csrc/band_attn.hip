@@ -221,6 +221,9 @@ __global__ __launch_bounds__(256) void band_attn_fwd_bf16_kernel(
         for (int j = 0; j < 8; ++j) x[j] *= scale;
         put_row(qs, row, scol, pack8(x));
     }
+    // k / v rows of this (b, h) as buffer resources: rows >= L read back as zeros (hardware range check)
+    const __amdgpu_buffer_rsrc_t kr = make_rsrc(kb, (uint32_t)(((long)(L - 1) * ldk + D) * 2));
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(vb, (uint32_t)(((long)(L - 1) * ldv + D) * 2));
     const int il = 32 * wi + l31;          // this lane's query row inside the tile
     const int iq = q0 + il;
     float m_run = -INFINITY, l_run = 0.f;
@@ -238,9 +241,8 @@ __global__ __launch_bounds__(256) void band_attn_fwd_bf16_kernel(
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int row = srow + 32 * it;
-            const bool ok = k0 + row < L;
-            put_row(ks, row, scol, ok ? *reinterpret_cast<const uint4*>(kb + (long)(k0 + row) * ldk + scol) : CWLT_U4Z);
-            put_row(vs, row, scol, ok ? *reinterpret_cast<const uint4*>(vb + (long)(k0 + row) * ldv + scol) : CWLT_U4Z);
+            put_row(ks, row, scol, buf_load16(kr, ((uint32_t)(k0 + row) * (uint32_t)ldk + scol) * 2));
+            put_row(vs, row, scol, buf_load16(vr, ((uint32_t)(k0 + row) * (uint32_t)ldv + scol) * 2));
         }
         if (tid < C) kvalid[tid] = (k0 + tid < L && (!mb || mb[k0 + tid] != 0.f)) ? 1.f : 0.f;
         __syncthreads();

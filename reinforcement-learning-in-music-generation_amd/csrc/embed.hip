@@ -142,12 +142,13 @@ __global__ __launch_bounds__(64, 2) void cw_embed_bwd_mfma_kernel(const int64_t*
     // this lane's slot of the 16 x 64 tile: row lane / 4 (16 rows), 16 columns starting at (lane % 4) * 16
     const int trow = lane >> 2, tcol = (lane & 3) * 16;
     uint4 p0, p1;
+    // this split's rows of the 64-column slab as a buffer resource: rows >= n read back as zeros
+    const __amdgpu_buffer_rsrc_t dr = make_rsrc(dp + r0 * ldd, n > 0 ? (uint32_t)(((long)(n - 1) * ldd + 64) * 2) : 0u);
 #define EB_LOAD(k0)                                                                              \
     {                                                                                            \
-        const bool ok = (k0) + trow < n;                                                         \
-        const bf16_t* src = dp + (r0 + (k0) + trow) * ldd + tcol;                                \
-        p0 = ok ? *reinterpret_cast<const uint4*>(src) : CWLT_U4Z;                                    \
-        p1 = ok ? *reinterpret_cast<const uint4*>(src + 8) : CWLT_U4Z;                                \
+        const uint32_t off = ((uint32_t)((k0) + trow) * (uint32_t)ldd + tcol) * 2;               \
+        p0 = buf_load16(dr, off);                                                                \
+        p1 = buf_load16(dr, off + 16);                                                           \
     }
     f32x16 acc[EB_MT][2];
 #pragma unroll
