@@ -57,7 +57,34 @@ def bench_wgrad():
               (N1, N2, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9))
 
 
+def bench_ffn1():
+    dev = torch.device("cuda:0")
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
+    x = torch.randn(M, 512, device=dev).bfloat16()
+    w = (torch.randn(2048, 512, device=dev) * 0.05).bfloat16()
+    b = torch.randn(2048, device=dev) * 0.1
+    h0 = torch.mm(x, w.t())
+    g0 = ops.gelu_fwd(h0, b, 0.1, 77)
+    h1, g1 = ops.ffn1_fused(x, w, b, 0.1, 77)
+    print("h: max |fused - hipBLASLt| = %.3e (max |h| %.2f); mismatching bf16 values: %.4f %%" %
+          ((h1.float() - h0.float()).abs().max().item(), h0.float().abs().max().item(),
+           100.0 * (h1 != h0).float().mean().item()))
+    g1ref = ops.gelu_fwd(h1, b, 0.1, 77)
+    print("g vs the separate kernel applied to the fused h: identical = %s" % torch.equal(g1, g1ref))
+    t0 = timeit(lambda: torch.mm(x, w.t()))
+    t1 = timeit(lambda: ops.gelu_fwd(h0, b, 0.1, 77))
+    t2 = timeit(lambda: ops.ffn1_fused(x, w, b, 0.1, 77))
+    fl = 2.0 * M * 512 * 2048
+    print("hipBLASLt mm %.1f us (%.0f TF) + gelu %.1f us = %.1f us ; fused %.1f us (%.0f TF on the GEMM flops)" %
+          (t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, (t0 + t1) * 1e3, t2 * 1e3, fl / t2 / 1e9))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ffn1":
+        from rlmg_amd import gemm_tuning
+        gemm_tuning.enable()
+        bench_ffn1()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
         bench_wgrad()
         sys.exit(0)
