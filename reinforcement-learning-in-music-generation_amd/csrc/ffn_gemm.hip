@@ -14,8 +14,12 @@
 //   main loop alone 537 us = 1 023 TFLOP/s (hipBLASLt incl. its C write: 585 us = 945 TFLOP/s),
 //   + tile to LDS 560 us, + the two output streams (2 GiB) 1 100 us  vs  585 + 487 = 1 072 us unfused.
 // The stores do not overlap the other resident workgroup's main loop (wave priorities and a start-up stagger
-// of the second resident workgroup changed nothing): the next step is a persistent workgroup that drains the
-// previous tile's outputs one 16-byte chunk per k-step of the current tile.
+// of the second resident workgroup changed nothing).  A persistent one-workgroup-per-CU variant that drained the
+// previous tile one 16-byte chunk per pair of k-steps of the current tile (main loop alone: 939 TFLOP/s with
+// 8 waves per CU) was also correct but slower still, 1 373 us: the activation + dropout hash cost ~30 VALU
+// instructions per element (~250 M wave-instructions per layer, 0.2-0.4 ms of issue time chip-wide) and with two
+// waves per SIMD that work does not hide under the MFMAs.  What would make the fusion pay: a cheaper mask
+// generator (no quarter-rate 32-bit multiplies) and dedicated epilogue waves.
 //
 // Workgroup = 8 waves (2 x 4), tile 128 rows x 256 columns, BK = 32.  Both operands are K-contiguous, so
 // fragments are plain 16-byte LDS reads (row stride 40 bf16 = 80 B).  The product is taken transposed (W
