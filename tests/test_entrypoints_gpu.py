@@ -118,6 +118,44 @@ def test_dqn_main_loop_short_run(cuda, tmp_path, monkeypatch):
         AIRL_model.D_MODEL, AIRL_model.N_LAYER, AIRL_model.N_HEAD = oldd
 
 
+@pytest.mark.parametrize("loop", ["dqn", "ppo"])
+def test_rl_main_loops_short_run_bf16(cuda, tmp_path, monkeypatch, loop):
+    """The drop-in RL loops in the throughput mode (CWLT_COMPUTE_DTYPE=bf16): bf16 trunk kernels, MFMA band
+    attention, grouped buffer scoring and the graphed rollout step run end to end with finite results."""
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.setenv("CWLT_COMPUTE_DTYPE", "bf16")
+    monkeypatch.setenv("CWLT_NO_PRETRAIN", "1")
+    import pickle
+    if loop == "dqn":
+        from rlmg_amd.dqn_policy import AIRL_model, IRL_dqn_train as T, config
+        old = _small(config.AgentConfig)
+        oldd = (AIRL_model.D_MODEL, AIRL_model.N_LAYER, AIRL_model.N_HEAD)
+        AIRL_model.D_MODEL, AIRL_model.N_LAYER, AIRL_model.N_HEAD = 128, 2, 2
+        monkeypatch.setattr(T, "NUM_SONGS", 3)
+        monkeypatch.setattr(T, "BUFFER_SIZE", 100)
+        try:
+            T.main()
+            with open("exp/IRL_reward.pickle", "rb") as f:
+                rew = pickle.load(f)
+            assert torch.isfinite(rew["Agent"]).all() and torch.isfinite(rew["Expert"]).all()
+        finally:
+            config.AgentConfig.update(old)
+            AIRL_model.D_MODEL, AIRL_model.N_LAYER, AIRL_model.N_HEAD = oldd
+    else:
+        from rlmg_amd.ppo_policy import config, ppo_train as P
+        old_a, old_d = _small(config.ActorConfig), _small(config.DiscriConfig)
+        monkeypatch.setattr(P, "NUM_SONGS", 1)
+        monkeypatch.setattr(P, "PPO_STEPS", 2)
+        try:
+            P.main()
+            with open("./ckpt/policy_loss.pickle", "rb") as f:
+                pl = pickle.load(f)["policy_loss"]
+            assert len(pl) == 1 and pl[0] == pl[0] and abs(pl[0]) < 1e6
+        finally:
+            config.ActorConfig.update(old_a)
+            config.DiscriConfig.update(old_d)
+
+
 def test_agent_pretrain_train_short_run(cuda, tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     from rlmg_amd.dqn_policy import agent_pretrain as A, config
