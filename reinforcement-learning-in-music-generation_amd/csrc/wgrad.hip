@@ -36,6 +36,7 @@ __device__ __forceinline__ bf16x8 tfrag(const bf16_t* t, int k0, int c0, int lan
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
+template <bool EDGE>
 __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       float* __restrict__ part, long M, int N1, int N2, long lda,
                                                       long ldb, long mslice) {
@@ -49,12 +50,13 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     // XCD-aware work mapping (speed only): workgroup ids are dealt round-robin over the 8 XCDs, so id % 8
     // labels the XCD.  All tiles of one token slice read the same A / B rows; giving a slice's tiles to ONE
     // XCD lets those re-reads hit that XCD's L2 instead of HBM.  S (number of slices) is a multiple of 8.
-    const int ntile = (N1 / TM) * (N2 / TN);
+    const int nt1 = (N1 + TM - 1) / TM, nt2 = (N2 + TN - 1) / TN;   // partial edge tiles allowed (N % 8 == 0)
+    const int ntile = nt1 * nt2;
     const int id = blockIdx.x;
     const int xcd = id & 7, idx = id >> 3;
     const int slice = xcd + 8 * (idx / ntile);
     const int tile = idx % ntile;
-    const int t1 = tile / (N2 / TN), t2 = tile % (N2 / TN);
+    const int t1 = tile / nt2, t2 = tile % nt2;
     const long m0 = (long)slice * mslice;
     const long m1 = min(M, m0 + mslice);
     const bf16_t* Ab = A + (long)t1 * TM;
@@ -65,9 +67,13 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
 
     // the slice's rows [m0, m1) of both operands as buffer resources: rows past the slice end read back as zeros
     // (hardware range check), offsets are 32-bit and relative to the slice start
+    // An edge tile narrower than 256 columns reads on into the next row (finite data whose products land in output
+    // columns that are never stored); the descriptor ends at the operand's last element so nothing past it is read.
     const long nrow = m1 > m0 ? m1 - m0 : 0;
-    const __amdgpu_buffer_rsrc_t ar = make_rsrc(Ab + m0 * lda, nrow ? (uint32_t)(((nrow - 1) * lda + TM) * 2) : 0u);
-    const __amdgpu_buffer_rsrc_t br = make_rsrc(Bb + m0 * ldb, nrow ? (uint32_t)(((nrow - 1) * ldb + TN) * 2) : 0u);
+    const long a_lim = min((nrow - 1) * lda + TM, (M - m0 - 1) * lda + (N1 - t1 * TM));
+    const long b_lim = min((nrow - 1) * ldb + TN, (M - m0 - 1) * ldb + (N2 - t2 * TN));
+    const __amdgpu_buffer_rsrc_t ar = make_rsrc(Ab + m0 * lda, nrow ? (uint32_t)(a_lim * 2) : 0u);
+    const __amdgpu_buffer_rsrc_t br = make_rsrc(Bb + m0 * ldb, nrow ? (uint32_t)(b_lim * 2) : 0u);
 #define WG_LOAD(RA, RB, ms)                                                                \
     {                                                                                      \
         const uint32_t row = (uint32_t)((ms) - m0) + srow;                                 \
@@ -120,13 +126,25 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
 #undef WG_LOAD
 #undef WG_STAGE
 #undef WG_COMPUTE
-    float* pb = part + ((long)slice * N1 + (long)t1 * TM + 64 * wn1) * N2 + (long)t2 * TN + 64 * wn2 + l31;
+    const int r0 = t1 * TM + 64 * wn1, c0 = t2 * TN + 64 * wn2 + l31;
+    float* pb = part + ((long)slice * N1 + r0) * N2 + c0;
+    if (!EDGE || (r0 + 64 <= N1 && t2 * TN + 64 * wn2 + 64 <= N2)) {          // interior wave tile: unguarded stores
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) pb[(long)(32 * i + acc_row(r, hf)) * N2 + 32 * j] = acc[i][j][r];
+                for (int r = 0; r < 16; ++r) pb[(long)(32 * i + acc_row(r, hf)) * N2 + 32 * j] = acc[i][j][r];
+    } else {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r0 + 32 * i + acc_row(r, hf) < N1 && c0 + 32 * j < N2)
+                        pb[(long)(32 * i + acc_row(r, hf)) * N2 + 32 * j] = acc[i][j][r];
+    }
 }
 
 // out[e] (+)= sum_s part[s * n + e], 4 floats per thread, fixed order
@@ -154,7 +172,7 @@ extern "C" {
 /* number of token-dimension splits (= partial tiles per output tile) the kernel will use */
 int cwlt_wgrad_splits(int64_t M, int N1, int N2) {
     if (M <= 0 || N1 <= 0 || N2 <= 0) return 1;
-    const long tiles = (long)(N1 / 256) * (N2 / 256);
+    const long tiles = (long)((N1 + 255) / 256) * ((N2 + 255) / 256);
     long s = tiles > 0 ? 256 / tiles : 8;       // about one 16-wave workgroup per CU ...
     s = s / 8 * 8;                              // ... in multiples of 8 (one slice group per XCD)
     if (s < 8) s = 8;
@@ -163,18 +181,19 @@ int cwlt_wgrad_splits(int64_t M, int N1, int N2) {
 }
 
 /* out (N1, N2) f32 dense (+)= A^T B;  a (M, N1), b (M, N2) bf16 row-major with row strides lda, ldb;
- * N1, N2 multiples of 256; part: cwlt_wgrad_splits(M, N1, N2) * N1 * N2 floats. */
+ * N1, N2 multiples of 8 (edge tiles of the 256 x 256 tiling may be partial); part: cwlt_wgrad_splits(M, N1, N2) * N1 * N2 floats. */
 int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64_t M, int N1, int N2, int64_t lda,
                     int64_t ldb, int accumulate, void* stream) {
     using namespace cwlt;
     if (!a || !b || !part || !out || M <= 0) return CWLT_ERR_ARG;
-    if (N1 <= 0 || N2 <= 0 || (N1 & 255) || (N2 & 255) || (lda & 7) || (ldb & 7) || lda < N1 || ldb < N2)
+    if (N1 <= 0 || N2 <= 0 || (N1 & 7) || (N2 & 7) || (lda & 7) || (ldb & 7) || lda < N1 || ldb < N2)
         return CWLT_ERR_ARG;
     const int S = cwlt_wgrad_splits(M, N1, N2);
     long mslice = (M + S - 1) / S;
     mslice = (mslice + 2 * wg::BK - 1) / (2 * wg::BK) * (2 * wg::BK);   // even number of BK steps
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(wg::wgrad_kernel, dim3((N1 / 256) * (N2 / 256) * S), dim3(1024), 0, st, (const bf16_t*)a,
+    const bool edge = (N1 & 255) || (N2 & 255);
+    hipLaunchKernelGGL(edge ? wg::wgrad_kernel<true> : wg::wgrad_kernel<false>, dim3(((N1 + 255) / 256) * ((N2 + 255) / 256) * S), dim3(1024), 0, st, (const bf16_t*)a,
                        (const bf16_t*)b, part, (long)M, N1, N2, (long)lda, (long)ldb, mslice);
     int e = (int)hipGetLastError();
     if (e) return e;

@@ -107,8 +107,8 @@ class CWTrunk(nn.Module):
         adt = self.compute_dtype
         embs = ops.cw_embed(x, self._tables(), adt)
         w, b = self.in_linear.weight, self.in_linear.bias
-        emb_linear = torch.nn.functional.linear(embs, w.to(adt), b.to(adt))
-        return emb_linear
+        lead = embs.shape[:-1]
+        return ops.linear(embs.reshape(-1, embs.shape[-1]), w, b).view(*lead, w.shape[0])
 
     def fused_logits(self, h):
         """One 512 x sum(n_token) GEMM for all heads -> (rows, W) with W = sum n_token padded to 64."""
@@ -120,7 +120,7 @@ class CWTrunk(nn.Module):
         if pad:
             w = torch.cat([w, w.new_zeros(pad, w.shape[1])], 0)
             b = torch.cat([b, b.new_zeros(pad)], 0)
-        return torch.nn.functional.linear(h.reshape(-1, h.shape[-1]), w.to(adt), b.to(adt))
+        return ops.linear(h.reshape(-1, h.shape[-1]), w, b)
 
     def split_logits(self, logits, lead_shape):
         outs, o = [], 0

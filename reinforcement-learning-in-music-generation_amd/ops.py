@@ -455,7 +455,7 @@ def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
 
 def wgrad_supported(a, b):
     return (a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.dim() == 2 and b.dim() == 2
-            and a.shape[1] % 256 == 0 and b.shape[1] % 256 == 0 and a.stride(1) == 1 and b.stride(1) == 1
+            and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0 and a.stride(1) == 1 and b.stride(1) == 1
             and a.stride(0) % 8 == 0 and b.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
 
 
@@ -473,6 +473,34 @@ def wgrad(a, b, out=None, accumulate=False):
     _call("cwlt_wgrad_bf16", _lib.dev(a, "a"), _lib.dev(b, "b"), _lib.dev(part), _lib.dev(out), M, N1, N2,
           a.stride(0), b.stride(0), 1 if accumulate else 0, _lib.stream_ptr())
     return out
+
+
+class LinearWgradFn(torch.autograd.Function):
+    """y = x @ w.T + b for a bf16 activation x and f32 master parameters (in_linear, the fused head projection).
+    Same forward as F.linear on the bf16 casts; the backward takes the weight gradient with the split-K MFMA kernel
+    straight in f32 (no bf16 rounding of the gradient, no .float() pass) and the bias gradient with the
+    deterministic column sum."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        w16 = w.to(x.dtype)
+        ctx.save_for_backward(x, w16)
+        return torch.addmm(b.to(x.dtype), x, w16.t())
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w16 = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.mm(dy, w16) if ctx.needs_input_grad[0] else None
+        dw = wgrad(dy, x) if wgrad_supported(dy, x) else torch.mm(dy.t(), x).float()
+        return dx, dw, colsum(dy)
+
+
+def linear(x, w, b):
+    """F.linear(x, w.to(x.dtype), b.to(x.dtype)) with the f32-gradient backward above when x is bf16."""
+    if x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and torch.is_grad_enabled():
+        return LinearWgradFn.apply(x, w, b)
+    return torch.nn.functional.linear(x, w.to(x.dtype), b.to(x.dtype))
 
 
 def colsum(x):

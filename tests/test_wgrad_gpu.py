@@ -8,7 +8,8 @@ from rlmg_amd import ops
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("M,N1,N2", [(32, 256, 256), (1000, 512, 256), (4096, 2048, 512), (777, 256, 1536)])
+@pytest.mark.parametrize("M,N1,N2", [(32, 256, 256), (1000, 512, 256), (4096, 2048, 512), (777, 256, 1536),
+                                     (1000, 384, 512), (4096, 512, 1216), (333, 8, 264), (64, 1216, 384)])   # edge tiles
 def test_wgrad_matches_fp64(cuda, M, N1, N2):
     g = torch.Generator().manual_seed(M)
     a = torch.randn(M, N1, generator=g).bfloat16()
@@ -31,3 +32,15 @@ def test_wgrad_strided_operands_and_determinism(cuda):
     assert torch.equal(r1, r2)
     ref = a.double().t() @ x.double()
     assert (r1.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_wgrad_edge_tile_on_column_slices(cuda):
+    """Partial 256-tiles read on into the next row: with operands that are column slices of wider tensors the
+    neighbouring columns must not leak into the result."""
+    wide_a = torch.randn(900, 640, device=cuda).bfloat16()
+    wide_b = torch.randn(900, 1400, device=cuda).bfloat16()
+    a, b = wide_a[:, 128:128 + 384], wide_b[:, 64:64 + 1216]
+    got = ops.wgrad(a, b)
+    ref = a.double().t() @ b.double()
+    assert got.shape == (384, 1216)
+    assert (got.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
