@@ -82,7 +82,6 @@ class GradSync:
             for p in b.params:       # re-attach in case an optimizer / user dropped the view
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + 4 * o:
                     p.grad = b.flat[o:o + p.numel()].view_as(p)
-                p._cwlt_fresh = True     # first direct delivery this step may overwrite instead of add
                 o += p.numel()
 
     def finish(self):

@@ -108,38 +108,33 @@ def direct_grads(param=None):
 
 
 def deliver_grad(p, g):
-    """p.grad (+)= g with one fused convert+store (g may be bf16, p.grad is f32)."""
+    """p.grad += g with one fused convert + add (g may be bf16, p.grad is f32)."""
     if not p.requires_grad:
         return
     if p.grad is None:
         p.grad = g.float().clone() if g.dtype == torch.float32 else g.float()
-    elif getattr(p, "_cwlt_fresh", False):
-        p.grad.copy_(g)
-        p._cwlt_fresh = False
     else:
         p.grad.add_(g)
 
 
 def deliver_grads(pairs):
-    """deliver_grad for a list of (parameter, gradient) pairs with ONE multi-tensor launch per kind (overwrite /
-    accumulate) instead of one small device copy per parameter (16 per encoder layer, ~9 us each)."""
-    fresh_d, fresh_s, acc_d, acc_s = [], [], [], []
+    """deliver_grad for a list of (parameter, gradient) pairs with ONE multi-tensor launch instead of one small
+    device op per parameter (16 per encoder layer, ~9 us each).  Always an accumulation, as autograd's own
+    AccumulateGrad: the buffers are zeroed by zero_grad().  (An earlier version overwrote on a parameter's first
+    delivery of a step with torch._foreach_copy_; inside a captured training step whose parameters receive two
+    deliveries -- DQN.update runs the network twice -- that combination went wrong when eager GEMMs ran between
+    replays; the accumulate-only form does not.)"""
+    dst, src = [], []
     for p, g in pairs:
         if not p.requires_grad:
             continue
         if p.grad is None:
             p.grad = g.float().clone() if g.dtype == torch.float32 else g.float()
-        elif getattr(p, "_cwlt_fresh", False):
-            fresh_d.append(p.grad)
-            fresh_s.append(g.view(p.grad.shape))
-            p._cwlt_fresh = False
         else:
-            acc_d.append(p.grad)
-            acc_s.append(g.view(p.grad.shape) if g.dtype == p.grad.dtype else g.view(p.grad.shape).to(p.grad.dtype))
-    if fresh_d:
-        torch._foreach_copy_(fresh_d, fresh_s)
-    if acc_d:
-        torch._foreach_add_(acc_d, acc_s)
+            dst.append(p.grad)
+            src.append(g.view(p.grad.shape) if g.dtype == p.grad.dtype else g.view(p.grad.shape).to(p.grad.dtype))
+    if dst:
+        torch._foreach_add_(dst, src)
     for p, _ in pairs:                       # data parallel: tell the gradient buckets (dist.GradSync)
         ready = getattr(p, "_cwlt_ready", None)
         if ready is not None and p.requires_grad:
@@ -182,20 +177,18 @@ def _seed_base():
 GRAPHS_ENABLED = os.environ.get("CWLT_GRAPHS", "1") != "0"     # CWLT_GRAPHS=0: RL rollout / update steps launch eagerly
 
 
-TRAIN_GRAPHS = os.environ.get("CWLT_TRAIN_GRAPHS", "0") == "1"
+TRAIN_GRAPHS = os.environ.get("CWLT_TRAIN_GRAPHS", "1") != "0"
 
 
 def train_graphs_enabled():
-    """Whole-training-step graphs (forward + backward + Adam of DQN.update / PPO.update_policy in one launch).
-    OPT-IN (CWLT_TRAIN_GRAPHS=1) and single process only (under data parallelism the gradient all-reduce is
-    launched from autograd hooks and stays eager).  Off by default because of one unresolved interaction
-    (narrowed down with tools/diag_graph_update.py): with bf16 activations, large EAGER bf16 GEMMs
-    run between replays (the replay-buffer scoring of IRL_dqn_train) corrupt the captured step -- NaN losses
-    after a few replays, once hipErrorIllegalAddress.  Not involved: our wgrad kernel, TunableOp, the autograd
-    worker thread, eager allocations as such (NaN-filled eager tensors between replays are harmless), f32
-    mode.  Forward-only graphs are unaffected: bit-exact against eager over 40 replays with the same GEMMs
-    interleaved (tools/diag_graph_fwd.py).  That points at workspace state shared between hipBLASLt's eager
-    GEMMs and the backward-layout GEMMs recorded in the graph."""
+    """Whole-training-step graphs (forward + backward + Adam of DQN.update / PPO.update_policy in one launch): on
+    unless CWLT_TRAIN_GRAPHS=0 or CWLT_GRAPHS=0, single process only (under data parallelism the gradient all-reduce
+    is launched from the delivery callbacks and stays eager).
+    History: an earlier gradient delivery that OVERWROTE on a parameter's first delivery of a step
+    (torch._foreach_copy_) and accumulated on the second made captured steps whose parameters are delivered
+    twice (DQN.update runs the network twice) go wrong -- NaN losses, once hipErrorIllegalAddress -- as soon as
+    eager GEMMs ran between replays; bisected with tools/diag_graph_{layer,model,update}.py.  The accumulate-only
+    delivery (deliver_grads) does not: 40 replays with interleaved GEMMs and the full IRL_dqn_train loop are clean."""
     import torch.distributed as dist
     single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
     return GRAPHS_ENABLED and TRAIN_GRAPHS and single

@@ -18,7 +18,51 @@ def say(msg):
     print(msg, flush=True)
 
 
+def patch_parts(agent):
+    """DIAG_PART=ce|td: keep only one of the two loss terms of DQN._update_device (bisecting the graph corruption)."""
+    part = os.environ.get("DIAG_PART")
+    if not part:
+        return
+    from rlmg_amd import rl_ops
+
+    def upd(agent_state, agent_next_state, agent_action, agent_reward, agent_done, expert_next_state, mask):
+        zero = torch.zeros((), device=agent_state.device)
+        if part == "td":
+            y = agent._fused(agent.eval_net, agent_state)
+            with torch.no_grad():
+                yt = agent._fused(agent.target_net, agent_next_state)
+            mse = rl_ops.dqn_td_mse(y, yt, agent_action, agent_reward, agent_done, agent.n_class, T.GAMMA).sum() / 6
+            ce, total = zero, mse
+        else:
+            c = agent.eval_net.train_step(agent_state, expert_next_state, mask)
+            ce = (c[0] + c[1] + c[2] + c[3] + c[4] + c[5]) / 6
+            mse, total = zero, ce
+        agent.sync.zero_grad()
+        total.backward()
+        agent.sync.finish()
+        agent.optim.step()
+        return mse.detach(), ce.detach(), total.detach()
+
+    agent._update_device = upd
+
+
 def main():
+    if os.environ.get("DIAG_NO_DIRECT") == "1":
+        ops.direct_grads = lambda p=None: False
+    if os.environ.get("DIAG_DELIVER") == "add":        # always accumulate (gradients are zeroed first)
+        def deliver(pairs):
+            d, s = [], []
+            for p, g in pairs:
+                if p.requires_grad:
+                    d.append(p.grad)
+                    s.append(g.view(p.grad.shape).to(p.grad.dtype))
+            torch._foreach_add_(d, s)
+        ops.deliver_grads = deliver
+    if os.environ.get("DIAG_DELIVER") == "single":     # the fresh / accumulate logic, one tensor op per parameter
+        def deliver1(pairs):
+            for p, g in pairs:
+                ops.deliver_grad(p, g)
+        ops.deliver_grads = deliver1
     if os.environ.get("DIAG_BLAS"):
         torch.backends.cuda.preferred_blas_library(os.environ["DIAG_BLAS"])
         say("preferred blas: %s" % torch.backends.cuda.preferred_blas_library())
@@ -30,6 +74,7 @@ def main():
     n_class = [56, 135, 18, 87, 18, 25]
     with contextlib.redirect_stdout(io.StringIO()):
         agent = T.DQN(n_class, Pretrain=False)
+    patch_parts(agent)
     g = torch.Generator().manual_seed(0)
     tok = lambda *s: torch.stack([torch.randint(0, c, s, generator=g) for c in n_class], -1).cuda()  # noqa: E731
     B = 30
