@@ -54,6 +54,8 @@ def main():
           "done": torch.zeros(B, 1)}
     m = torch.ones(B, 50).cuda()
     with contextlib.redirect_stdout(io.StringIO()):
+        for _ in range(4):                                  # eager steps + the capture of the update graph
+            agent.update(tr, dict(tr), m, False, 0)
         t = timed(lambda: agent.update(tr, dict(tr), m, False, 0))
     print("DQN.update (batch 30)              %8.2f ms" % t)
     x = tok(1, 50)
