@@ -83,6 +83,7 @@ def main():
     torch.manual_seed(100 + rank)
 
     def iteration():
+        torch.cuda.synchronize()            # queued update graphs of the previous iteration must not count as rollout
         t_roll0 = time.perf_counter()
         state = expert[:, :W].clone()
         states = torch.empty((E, R, W, 6), dtype=torch.int64, device=dev)

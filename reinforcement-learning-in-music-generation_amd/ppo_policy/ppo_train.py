@@ -139,6 +139,23 @@ class PPO(object):
         return action, logp, value_state
 
     def update_rollouts(self, states, old_logp_int, advs, rets, expert, mask, group=8, clip=None):
+        """`_update_rollouts_device`, replayed as one hipGraph when the step is launch-bound (few tokens) and graphs
+        are enabled; eager otherwise (at 64 x 1024 the GPU is the bottleneck and a capture would only hold memory)."""
+        clip = PPO_CLIP if clip is None else clip
+        E, R, W = states.shape[0], states.shape[1], states.shape[2]
+        if ops.train_graphs_enabled() and E * R * W <= 32768:
+            key = (int(group), float(clip))
+            graphs = self.__dict__.setdefault("_graph_rollouts", {})
+            if key not in graphs:
+                graphs[key] = ops.GraphedCall(
+                    lambda st, ol, ad, rt, ex, mk: self._update_rollouts_device(st, ol, list(ad), list(rt), ex, mk,
+                                                                                group, clip) or st.new_zeros(()),
+                    grad=True)
+            graphs[key](states, old_logp_int, torch.stack(list(advs)), torch.stack(list(rets)), expert, mask.float())
+            return
+        self._update_rollouts_device(states, old_logp_int, advs, rets, expert, mask, group, clip)
+
+    def _update_rollouts_device(self, states, old_logp_int, advs, rets, expert, mask, group=8, clip=None):
         """One PPO inner step (the body of update_policy's loop, ppo_train.py:360-420) over R rollouts run in
         lock-step -- the many-rollout generalisation bench_ppo.py measures (BASELINE configs[2]).
         states (E, R, W, 6) int64, old_logp_int (E, R, NA, 6) int64 (the buffer's `.long()` log-probs),
