@@ -79,7 +79,27 @@ def bench_ffn1():
           (t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, (t0 + t1) * 1e3, t2 * 1e3, fl / t2 / 1e9))
 
 
+def bench_gemm_core():
+    """The fused-FFN kernel's GEMM core on the model's other forward shapes vs torch.mm (it writes two outputs)."""
+    dev = torch.device("cuda:0")
+    M = 262144
+    for N, K in ((2048, 512), (512, 2048), (512, 512), (1536, 512)):
+        x = torch.randn(M, K, device=dev).bfloat16()
+        w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+        b = torch.zeros(N, device=dev)
+        t0 = timeit(lambda: torch.mm(x, w.t()))
+        t1 = timeit(lambda: ops.ffn1_fused(x, w, b, 0.0, 0))
+        fl = 2.0 * M * N * K
+        print("N=%4d K=%4d  torch.mm %7.1f us (%5.0f TF)   cwlt core + 2 outputs %7.1f us (%5.0f TF)" %
+              (N, K, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "gemmcore":
+        from rlmg_amd import gemm_tuning
+        gemm_tuning.enable()
+        bench_gemm_core()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ffn1":
         from rlmg_amd import gemm_tuning
         gemm_tuning.enable()
