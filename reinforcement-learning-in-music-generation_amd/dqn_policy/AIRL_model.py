@@ -42,16 +42,40 @@ class LongFormer(CWLongformerBase):
         """forward() of consecutive batches of `group` windows, (n, window, 6) -> (n, 1), with the Longformer body
         run over up to `windows_per_pass` windows at a time.  Equal to calling forward() batch by batch: every
         op before the score classifier acts on one window (or one token) alone; the classifier's BatchNorm1d is
-        what sees a batch, so it is applied -- running statistics included -- per group, in order."""
+        what sees a batch, so it is applied -- running statistics included -- per group (`_classify_groups`)."""
         n = data.shape[0]
         if n % group:
             raise ValueError("score_in_groups needs a whole number of groups")
-        out = []
-        for s in range(0, n, windows_per_pass - windows_per_pass % group):
-            e = min(n, s + windows_per_pass - windows_per_pass % group)
-            mean = self._encode(data[s:e], masks[s:e]).float().mean(dim=1)
-            out += [self.score_classifier(mean[g0:g0 + group]) for g0 in range(0, e - s, group)]
-        return torch.cat(out, 0)
+        means = []
+        step = windows_per_pass - windows_per_pass % group
+        for s in range(0, n, step):
+            e = min(n, s + step)
+            means.append(self._encode(data[s:e], masks[s:e]).float().mean(dim=1))
+        return self._classify_groups(torch.cat(means, 0), group)
+
+    def _classify_groups(self, mean, group):
+        """score_classifier on consecutive groups of `group` rows of `mean` (n, d_model), all groups in one pass.
+        BatchNorm1d in train mode normalises each group with its own statistics and moves the running statistics
+        once per group, in order: running <- (1 - m) running + m stat_g, unrolled here to a weighted sum."""
+        lin0, bn, _, lin3, _, lin5, _ = self.score_classifier
+        F = torch.nn.functional
+        if not (bn.training and bn.track_running_stats and bn.momentum is not None):
+            return torch.cat([self.score_classifier(mean[g0:g0 + group]) for g0 in range(0, mean.shape[0], group)], 0)
+        G = mean.shape[0] // group
+        z = F.linear(mean, lin0.weight, lin0.bias).view(G, group, -1)
+        mu = z.mean(dim=1)
+        var_b = z.var(dim=1, unbiased=False)
+        zn = (z - mu[:, None]) * torch.rsqrt(var_b[:, None] + bn.eps) * bn.weight + bn.bias
+        with torch.no_grad():
+            m = bn.momentum
+            w = m * (1.0 - m) ** torch.arange(G - 1, -1, -1, device=mean.device, dtype=mean.dtype)
+            var_u = var_b * (group / max(group - 1, 1))
+            bn.running_mean.mul_((1.0 - m) ** G).add_((w[:, None] * mu).sum(0))
+            bn.running_var.mul_((1.0 - m) ** G).add_((w[:, None] * var_u).sum(0))
+            bn.num_batches_tracked += G
+        y = torch.tanh(zn.view(G * group, -1))
+        y = torch.tanh(F.linear(y, lin3.weight, lin3.bias))
+        return torch.sigmoid(F.linear(y, lin5.weight, lin5.bias))
 
     def token_forward(self, data, target, loss_mask):
         """Mean of the 6 token CE losses of the discriminator's heads (AIRL_model.py:131-170).  compute_CEloss
