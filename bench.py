@@ -121,7 +121,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=256, help="sequences per GPU")
+    ap.add_argument("--batch", type=int, default=512, help="sequences per GPU")
     ap.add_argument("--seq", type=int, default=1024)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -261,6 +261,7 @@ def main():
                        "parallelism": "dp%d" % world, "dropout": 0.1, "params": 38982227,
                        "gemm_table": str(tuned)},
             "final_loss": round(float(loss.item()), 4), "replica_spread": replica_spread,
+            "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
             "model_mfma_frac": round(tokens_per_s / world * FLOP_PER_TOKEN / MFMA_BF16_PEAK, 4),
             "roofline": roofline, "kernels": kernels,
         }

@@ -34,7 +34,8 @@ def test_bench_tables_cover_reported_entry_points():
     import bench
     d = json.load(open(os.path.join(ROOT, "profiles", "r01_final_bench.json")))
     for name, row in d["kernels"].items():
-        has_bytes = bench.algorithmic_bytes(name, 256, 1024, s=2)
-        has_flops = bench.algorithmic_flops(name, 256, 1024)
+        B, T = d["config"]["per_gpu_batch"], d["config"]["seq_len"]
+        has_bytes = bench.algorithmic_bytes(name, B, T, s=2)
+        has_flops = bench.algorithmic_flops(name, B, T)
         assert has_bytes or has_flops, name
         assert (row["GB/s"] is not None) == bool(has_bytes)

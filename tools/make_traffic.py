@@ -2,7 +2,7 @@
 
     rocprofv3 --pmc FETCH_SIZE -d gpurun_out/pmc_fetch -o f --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer
     rocprofv3 --pmc WRITE_SIZE -d gpurun_out/pmc_write -o w --output-format csv -- python3 bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timer
-    python tools/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write
+    python tools/make_traffic.py gpurun_out/pmc_fetch gpurun_out/pmc_write [batch]
 
 HBM bytes per LAUNCH of each C-ABI entry point = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and
 FETCH_SIZE counts 16-byte coalesced reads at half size on gfx950 (MI355X_MICROARCH.md, HBM / rocprofv3 section).
@@ -48,7 +48,7 @@ def main():
     for ent in sorted(ft):
         if fn[ent] and wn.get(ent):
             out[ent] = int(round((2.0 * ft[ent] / fn[ent] + wt[ent] / wn[ent]) * 1024))
-    meta = {"batch": 256, "seq": 1024, "dtype": "bf16",
+    meta = {"batch": int(sys.argv[3]) if len(sys.argv) > 3 else 512, "seq": 1024, "dtype": "bf16",
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1; "
                       "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction for 16-B "
                       "coalesced reads, MI355X_MICROARCH.md); tools/make_traffic.py",
