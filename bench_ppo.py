@@ -52,7 +52,7 @@ def main():
 
     import rlmg_amd  # noqa: F401
     from rlmg_amd import dist as rdist, gemm_tuning, ops, rl_ops
-    from rlmg_amd.ppo_policy import ppo_train as P
+    from rlmg_amd.ppo_policy import config as pcfg, ppo_train as P
 
     if args.no_graphs:
         ops.GRAPHS_ENABLED = False
@@ -71,6 +71,11 @@ def main():
     P.N_ACTIONS = P.NUM_ACTION = NA
     P.N_STATES = P.WINDOW_SIZE = W
     n_token = [49, 19, 19, 89, 67, 25]
+    if W + 2 > pcfg.DiscriConfig["MAX_SEQ"]:
+        # BASELINE configs[4] (window 4096) exceeds the reward model's position table (2048 in the reference): the
+        # weights are random here anyway, so the table is simply built large enough
+        pcfg.DiscriConfig["MAX_SEQ"] = W + 2
+        log("reward model position table enlarged to %d for window %d" % (W + 2, W))
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         agent = P.PPO(n_token, Pretrain=False)
