@@ -118,3 +118,19 @@ def test_empty_and_ragged_inputs(cuda):
     with pytest.raises(RuntimeError):                                # head_dim != 64 is refused, not mis-computed
         bad = torch.randn(1, 4, 2, 32, device=cuda)
         ops.causal_linear_attention(bad, bad, bad)
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 1e-4), (torch.bfloat16, 2.0 ** -7)])
+def test_scan_forward_backward_at_t4096_vs_oracle(cuda, dtype, tol):
+    """The long-context window of BASELINE configs[4] (T = 4096 = 64 chunks of state carried in accumulators):
+    forward and all three gradients against the f64 oracle on the same (rounded) inputs."""
+    from oracle import cla as ocla
+    g0 = torch.Generator().manual_seed(4096)
+    q, k, v, g = (torch.randn(1, 4096, 2, 64, generator=g0).to(dtype) for _ in range(4))
+    ref = ocla.cla_grads(q.double(), k.double(), v.double(), g.double())
+    qd, kd, vd = (t.to(cuda).requires_grad_(True) for t in (q, k, v))
+    out = ops.causal_linear_attention(qd, kd, vd)
+    out.backward(g.to(cuda))
+    for got, r in zip((out, qd.grad, kd.grad, vd.grad), ref):
+        err = (got.detach().cpu().double() - r).abs().max().item()
+        assert err <= tol * max(1.0, r.abs().max().item()), err
