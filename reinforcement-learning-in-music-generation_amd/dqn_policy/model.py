@@ -16,7 +16,7 @@ if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 import rlmg_amd  # noqa: E402,F401
 from rlmg_amd.cw_transformer import CWTrunk, Embeddings, PositionalEncoding  # noqa: E402,F401
-from rlmg_amd.sampling import nucleus, sampling, softmax_with_temperature, weighted_sampling  # noqa: E402,F401
+from rlmg_amd.sampling import nucleus, sample_cw, sampling, softmax_with_temperature, weighted_sampling  # noqa: E402,F401
 
 try:
     from config import AgentConfig
@@ -53,11 +53,4 @@ class LinearTransformer(CWTrunk):
     def forward_output_sampling(self, h):
         """Generation-time sampling of the next CW token (model.py:259-298) -> np.ndarray[6]."""
         y = [t.float() for t in self.forward_output(h)]
-        return np.array([
-            sampling(y[0], t=1.2, p=0.9),    # tempo
-            sampling(y[1], p=0.99),          # chord
-            sampling(y[2], t=1.2),           # barbeat
-            sampling(y[3], p=0.9),           # pitch
-            sampling(y[4], t=2, p=0.9),      # duration
-            sampling(y[5], t=5),             # velocity
-        ])
+        return sample_cw(y)             # draws in the reference's order: tempo, barbeat, chord, pitch, ...

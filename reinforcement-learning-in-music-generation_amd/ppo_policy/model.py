@@ -16,7 +16,7 @@ if _ROOT not in sys.path:
 import rlmg_amd  # noqa: E402,F401
 from rlmg_amd.cw_transformer import ATTRS, CWTrunk, Embeddings, PositionalEncoding  # noqa: E402,F401
 from rlmg_amd.discriminator import CWLongformerBase  # noqa: E402
-from rlmg_amd.sampling import nucleus, sampling, softmax_with_temperature, weighted_sampling  # noqa: E402,F401
+from rlmg_amd.sampling import nucleus, sample_cw, sampling, softmax_with_temperature, weighted_sampling  # noqa: E402,F401
 
 try:
     from config import ActorConfig, DiscriConfig
@@ -46,10 +46,7 @@ class Actor_Transformer(CWTrunk):
 
     def forward_output_sampling(self, h):
         y = [t.float() for t in self.forward_output(h)]
-        return np.array([
-            sampling(y[0], t=1.2, p=0.9), sampling(y[1], p=0.99), sampling(y[2], t=1.2),
-            sampling(y[3], p=0.9), sampling(y[4], t=2, p=0.9), sampling(y[5], t=5),
-        ])
+        return sample_cw(y)             # ppo_policy/model.py:264-269 draw order
 
 
 class Critic_Transformer(CWTrunk):

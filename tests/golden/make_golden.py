@@ -238,6 +238,36 @@ def airl_grads_small():
     np.savez_compressed(os.path.join(HERE, "airl_grads_small.npz"), **out)
 
 
+def dqn_generation_small():
+    """Generation (dqn_policy/testing-no-type-cp.py:126-179 loop, driven here on the CPU): the reference's own
+    LinearTransformer(is_training=False) -- forward_hidden(x, memory, is_training=False) one token at a time from
+    the Bar token, then ITS forward_output_sampling (its numpy samplers, seeded np.random).  Stored: the token
+    stream, and per step the hidden row and the six logit vectors the samplers saw."""
+    config, model = _import_reference("dqn_policy")
+    config.AgentConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    n_class = [56, 135, 18, 87, 18, 25]
+    import io
+    import contextlib
+    with contextlib.redirect_stdout(io.StringIO()):
+        net = fill_params(model.LinearTransformer(n_class, is_training=False), seed=81).eval()
+    steps = 48
+    np.random.seed(20240)
+    tokens, hs, logits = [np.array([0, 0, 1, 0, 0, 0])], [], []
+    with torch.no_grad():
+        h, memory = net.forward_hidden(torch.from_numpy(tokens[0]).long().view(1, 1, 6), None, is_training=False)
+        for _ in range(steps):
+            hs.append(h.numpy().reshape(-1))
+            logits.append(np.concatenate([y.numpy().reshape(-1) for y in net.forward_output(h, None)]))
+            nxt = net.forward_output_sampling(h)
+            tokens.append(np.asarray(nxt))
+            h, memory = net.forward_hidden(torch.from_numpy(np.asarray(nxt)).long().view(1, 1, 6), memory,
+                                           is_training=False)
+    out = {"tokens": np.stack(tokens).astype(np.int64), "h": np.stack(hs), "logits": np.stack(logits),
+           "n_class": np.array(n_class), "np_seed": np.array(20240), "fill_seed": np.array(81)}
+    np.savez_compressed(os.path.join(HERE, "dqn_generation_small.npz"), **out)
+    config.AgentConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     dqn_small()
@@ -246,6 +276,7 @@ if __name__ == "__main__":
     ppo_reward_small()
     airl_small()
     airl_grads_small()
+    dqn_generation_small()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

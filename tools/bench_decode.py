@@ -1,0 +1,53 @@
+"""Generation throughput: CW tokens/s of the recurrent decode step at the repo dims (512/12/8), one song.
+    python tools/bench_decode.py [--tokens 512] [--no-graph]
+Prints one JSON line per mode.  Includes the host-side numpy sampling (as the reference's loop does) and,
+separately, the device-only rate (step without sampling)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import generation  # noqa: E402
+from rlmg_amd.sampling import sample_cw  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--tokens", type=int, default=512)
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--dtype", default="f32")
+    a = ap.parse_args()
+    from rlmg_amd.dqn_policy import model
+    n_class = [56, 135, 18, 87, 18, 25]
+    torch.manual_seed(0)
+    net = model.LinearTransformer(n_class, is_training=False).cuda().eval()
+    if a.dtype == "bf16":
+        net.compute_dtype = torch.bfloat16
+    for graph in ([False] if a.no_graph else [False, True]):
+        sess = generation.DecodeSession(net, graph=graph)
+        np.random.seed(0)
+        tok = generation.INIT_CW[0]
+        for _ in range(8):
+            tok = sample_cw(sess.split(sess.step(tok)))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(a.tokens):
+            tok = sample_cw(sess.split(sess.step(tok)))
+        t1 = time.perf_counter()
+        for _ in range(a.tokens):
+            sess.step(tok)
+        t2 = time.perf_counter()
+        print(json.dumps({"metric": "decode CW-tokens/s (1 song)", "graph": graph, "dtype": a.dtype,
+                          "with_sampling": round(a.tokens / (t1 - t0), 1),
+                          "device_only": round(a.tokens / (t2 - t1), 1),
+                          "us_per_token_device": round((t2 - t1) / a.tokens * 1e6, 1)}), flush=True)
+
+
+if __name__ == "__main__":
+    main()
