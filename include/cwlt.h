@@ -240,6 +240,51 @@ int cwlt_recurrent_cla_step(const void* q, const void* k, const void* v, float* 
                             int N, int H, int head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
                             float eps, int dtype, void* stream);
 
+/* ---- generation: one CW token through the whole recurrent-form model (f32) --------------------------
+ * Replaces the per-token body of the reference's generation loop: `forward_hidden(input_, memory,
+ * is_training=False)` (dqn_policy/testing-no-type-cp.py:150,166 -> dqn_policy/model.py:200-238 -> the
+ * RecurrentEncoderBuilder product of dqn_policy/model.py:141-150) followed by the six head projections of
+ * `forward_output_sampling` (dqn_policy/model.py:273-278); likewise ppo_policy/inference.py:78-160 over
+ * ppo_policy/model.py:200-262.  All pointers are device pointers unless marked HOST; the structs themselves
+ * are HOST memory, read during the call only.  Per-song state S / Z is updated in place. */
+typedef struct cwlt_decode_layer {
+    const float *wqkv, *bqkv;     /* (3D, D), (3D): query | key | value projection rows stacked */
+    const float *wo, *bo;         /* (D, D), (D): out_projection */
+    const float *ln1_w, *ln1_b;   /* norm1 */
+    const float *w1, *b1;         /* (F, D), (F): linear1 */
+    const float *w2, *b2;         /* (D, F), (D): linear2 */
+    const float *ln2_w, *ln2_b;   /* norm2 */
+    float *S, *Z;                 /* (n_songs, H, 64, 64), (n_songs, H, 64) f32 recurrent state */
+} cwlt_decode_layer;
+
+typedef struct cwlt_decode_model {
+    int n_layer, n_head, d_model, d_ff, n_attr, emb_width, n_logits;
+    float eps_ln, eps_attn;            /* 1e-5, 1e-6 in the reference */
+    const void* const* tables;         /* HOST array of n_attr device pointers (f32 embedding tables) */
+    const int* widths;                 /* HOST (n_attr): embedding widths, sum = emb_width */
+    const int* nrows;                  /* HOST (n_attr): vocabulary sizes */
+    const float *w_in, *b_in;          /* (D, emb_width), (D): in_linear */
+    const float* pe0;                  /* (D): row 0 of the positional-encoding buffer (pos_emb.pe) */
+    const cwlt_decode_layer* layers;   /* HOST array of n_layer */
+    const float *lnf_w, *lnf_b;        /* final encoder norm (NULL: none) */
+    const float *w_heads, *b_heads;    /* (n_logits, D), (n_logits): the proj_* heads stacked */
+} cwlt_decode_model;
+
+/* floats of workspace PER SONG (-1: unsupported model: needs d_model = 64*n_head <= 2048, d_ff <= 2048,
+ * emb_width <= 2048, all multiples of 4) */
+int64_t cwlt_decode_workspace_floats(const cwlt_decode_model* m);
+/* tokens: (n_songs, n_attr) int64; work: n_songs * cwlt_decode_workspace_floats(m) f32 (16-byte aligned);
+ * hidden: (n_songs, D) f32 or NULL -- what forward_hidden returns; logits: (n_songs, n_logits) f32. */
+int cwlt_decode_step(const cwlt_decode_model* m, const int64_t* tokens, float* work, float* hidden,
+                     float* logits, int n_songs, void* stream);
+/* The step's building block: out[n, r] = epi(W[r, :] . pro(xin[n, :]) + bias[r]); pro = optional LayerNorm
+ * (ln_w, ln_b) and an optional second one (ln2_w, ln2_b), the normalised vector also stored to x_out when given;
+ * epi = exact-erf GELU when act == 1, then + res[n, r] when res != NULL.  K % 4 == 0, K <= 2048. */
+int cwlt_decode_gemv(const float* W, const float* bias, const float* xin, const float* ln_w,
+                     const float* ln_b, const float* ln2_w, const float* ln2_b, float eps,
+                     const float* res, float* out, float* x_out, int n_out, int K, int act, int n_songs,
+                     int64_t ld_x, int64_t ld_res, int64_t ld_out, int64_t ld_xo, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

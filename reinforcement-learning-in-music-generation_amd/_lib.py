@@ -11,13 +11,32 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
 _c_f32 = ctypes.c_float
 _c_u64 = ctypes.c_uint64
 _ptr = ctypes.c_void_p
+
+
+
+class DecodeLayer(ctypes.Structure):
+    """cwlt_decode_layer (include/cwlt.h)."""
+    _fields_ = [(n, ctypes.c_void_p) for n in ("wqkv", "bqkv", "wo", "bo", "ln1_w", "ln1_b", "w1", "b1", "w2", "b2",
+                                               "ln2_w", "ln2_b", "S", "Z")]
+
+
+class DecodeModel(ctypes.Structure):
+    """cwlt_decode_model (include/cwlt.h)."""
+    _fields_ = ([(n, ctypes.c_int) for n in ("n_layer", "n_head", "d_model", "d_ff", "n_attr", "emb_width",
+                                             "n_logits")] +
+                [("eps_ln", ctypes.c_float), ("eps_attn", ctypes.c_float),
+                 ("tables", ctypes.POINTER(ctypes.c_void_p)), ("widths", ctypes.POINTER(ctypes.c_int)),
+                 ("nrows", ctypes.POINTER(ctypes.c_int)), ("w_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p),
+                 ("pe0", ctypes.c_void_p), ("layers", ctypes.POINTER(DecodeLayer)), ("lnf_w", ctypes.c_void_p),
+                 ("lnf_b", ctypes.c_void_p), ("w_heads", ctypes.c_void_p), ("b_heads", ctypes.c_void_p)])
+
 
 # name -> argtypes; restype is always int (status)
 _SIGNATURES = {
@@ -45,6 +64,9 @@ _SIGNATURES = {
     "cwlt_wgrad_splits": [_c_i64, _c_int, _c_int],
     "cwlt_wgrad_bf16": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_recurrent_cla_step": [_ptr] * 6 + [_c_int] * 3 + [_c_i64] * 4 + [_c_f32, _c_int, _ptr],
+    "cwlt_decode_workspace_floats": [ctypes.POINTER(DecodeModel)],
+    "cwlt_decode_step": [ctypes.POINTER(DecodeModel), _ptr, _ptr, _ptr, _ptr, _c_int, _ptr],
+    "cwlt_decode_gemv": [_ptr] * 7 + [_c_f32] + [_ptr] * 3 + [_c_int] * 4 + [_c_i64] * 4 + [_ptr],
     "cwlt_heads_blocks": [_c_i64],
     "cwlt_heads_fwd": [_ptr, _ptr, _c_int] + [_ptr] * 7 + [_c_i64, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_heads_ce_bwd": [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
@@ -81,7 +103,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = _c_int
+        fn.restype = _c_i64 if name == "cwlt_decode_workspace_floats" else _c_int
     got = lib.cwlt_abi_version()
     if got != ABI_VERSION:
         raise ImportError("libcwlt.so ABI version %d, binding expects %d -- rebuild" % (got, ABI_VERSION))

@@ -12,12 +12,13 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 OBJ = os.path.join(CSRC, ".obj")
 LIB = os.path.join(PKG, "libcwlt.so")
+INCLUDE = os.path.join(os.path.dirname(PKG), "include")          # the public C-ABI header (cwlt.h)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 # -amdgpu-mfma-vgpr-form: MFMA accumulators stay in VGPRs.  The kernels that feed accumulators back as operands
 # (scan states, score tiles) otherwise pay a v_accvgpr_read/write per element per use (~20 % of the scan's VALU
 # instructions) and use MORE registers in total (146 VGPR + 96 AGPR vs 180 VGPR for the forward scan).
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-mllvm", "-amdgpu-mfma-vgpr-form"]
+         "-mllvm", "-amdgpu-mfma-vgpr-form", "-I", INCLUDE]
 
 
 def _sources():
@@ -34,6 +35,7 @@ def _stale(obj, deps):
 def build(force=False, verbose=False):
     os.makedirs(OBJ, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    headers.append(os.path.join(INCLUDE, "cwlt.h"))
     headers.append(os.path.abspath(__file__))      # a change of flags rebuilds everything
     jobs = []
     objs = []

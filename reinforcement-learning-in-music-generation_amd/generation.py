@@ -9,10 +9,13 @@ dqn_policy/agent_pretrain.py:636-706, ppo_policy/inference.py:78-160):
 `DecodeSession` is the device side of one song: the 12 x [S (1,H,64,64), Zs (1,H,64)] state lives in HBM
 and is updated in place, the CW token is written into a static (1,1,6) buffer, and the whole per-token
 step (embedding gather -> in_linear -> 12 recurrent layers -> final LN -> fused 6-head GEMV) is ONE
-hipGraph replay; the only host traffic per token is 48 B of ids in and sum(n_token) f32 logits out.
+hipGraph replay of `cwlt_decode_step` (csrc/decode.hip: GEMVs with LayerNorm prologues and bias / GELU /
+residual epilogues, 63 launches per token); the only host traffic per token is 48 B of ids in and
+sum(n_token) f32 logits out.
 Sampling stays on the host with numpy, in the reference's order of draws, so that a seeded
 `np.random` reproduces the reference's token stream.
 """
+import ctypes
 import json
 import os
 import time
@@ -26,10 +29,91 @@ from .sampling import sample_cw
 INIT_CW = np.array([[0, 0, 1, 0, 0, 0]])          # "Bar" token, testing-no-type-cp.py:135-137
 
 
-class DecodeSession:
-    """Per-song decode state + the captured one-token step.  `step(ids) -> (sum n_token,) f32 numpy logits`."""
+class _FusedPlan:
+    """Host description of the model for `cwlt_decode_step` (include/cwlt.h: cwlt_decode_model): stacked
+    QKV / head weights, device pointers of every parameter, the per-song state and workspace.  Holds references
+    to every tensor whose pointer it hands out.  Built once per song (`DecodeSession.reset` rebuilds it, so
+    weights loaded between songs are picked up)."""
 
-    def __init__(self, model, graph=None):
+    def __init__(self, model, memory, n_songs):
+        from . import _lib
+        lib = _lib.load()
+        enc = model.transformer_encoder
+        f32 = lambda t: t.detach().float().contiguous()
+        self.keep = []
+
+        def P(t):
+            t = f32(t)
+            self.keep.append(t)
+            return _lib.dev(t).value
+
+        layers = (_lib.DecodeLayer * len(enc.layers))()
+        for i, (L, (S, Z)) in enumerate(zip(enc.layers, memory)):
+            at = L.attention
+            d = layers[i]
+            d.wqkv = P(torch.cat([at.query_projection.weight, at.key_projection.weight, at.value_projection.weight], 0))
+            d.bqkv = P(torch.cat([at.query_projection.bias, at.key_projection.bias, at.value_projection.bias], 0))
+            d.wo, d.bo = P(at.out_projection.weight), P(at.out_projection.bias)
+            d.ln1_w, d.ln1_b = P(L.norm1.weight), P(L.norm1.bias)
+            d.w1, d.b1 = P(L.linear1.weight), P(L.linear1.bias)
+            d.w2, d.b2 = P(L.linear2.weight), P(L.linear2.bias)
+            d.ln2_w, d.ln2_b = P(L.norm2.weight), P(L.norm2.bias)
+            d.S, d.Z = _lib.dev(S).value, _lib.dev(Z).value
+            for nrm in (L.norm1, L.norm2):
+                if abs(nrm.eps - enc.layers[0].norm1.eps) > 0:
+                    raise RuntimeError("decode step needs one LayerNorm eps for the whole encoder")
+        tables = model._tables()
+        heads = model._heads()
+        m = _lib.DecodeModel()
+        m.n_layer, m.n_head = len(enc.layers), enc.layers[0].attention.n_heads
+        m.d_model, m.d_ff = model.d_model, enc.layers[0].linear1.out_features
+        m.n_attr, m.emb_width = len(tables), sum(t.shape[1] for t in tables)
+        m.n_logits = sum(h.out_features for h in heads)
+        m.eps_ln, m.eps_attn = enc.layers[0].norm1.eps, ops.CLA_EPS
+        self._tables = (ctypes.c_void_p * len(tables))(*[P(t) for t in tables])
+        self._widths = _lib.int_array([t.shape[1] for t in tables])
+        self._nrows = _lib.int_array([t.shape[0] for t in tables])
+        m.tables = ctypes.cast(self._tables, ctypes.POINTER(ctypes.c_void_p))
+        m.widths = ctypes.cast(self._widths, ctypes.POINTER(ctypes.c_int))
+        m.nrows = ctypes.cast(self._nrows, ctypes.POINTER(ctypes.c_int))
+        m.w_in, m.b_in = P(model.in_linear.weight), P(model.in_linear.bias)
+        m.pe0 = P(model.pos_emb.pe[0, 0])
+        self._layers = layers
+        m.layers = ctypes.cast(layers, ctypes.POINTER(_lib.DecodeLayer))
+        if enc.norm is not None:
+            if enc.norm.eps != enc.layers[0].norm1.eps:
+                raise RuntimeError("decode step needs one LayerNorm eps for the whole encoder")
+            m.lnf_w, m.lnf_b = P(enc.norm.weight), P(enc.norm.bias)
+        m.w_heads = P(torch.cat([h.weight for h in heads], 0))
+        m.b_heads = P(torch.cat([h.bias for h in heads], 0))
+        self.model = m
+        per_song = lib.cwlt_decode_workspace_floats(ctypes.byref(m))
+        if per_song <= 0:
+            raise RuntimeError("cwlt_decode_step does not support this model shape (d_model %d, d_ff %d)"
+                               % (m.d_model, m.d_ff))
+        dev = memory[0][0].device
+        self.work = torch.zeros(n_songs * per_song, dtype=torch.float32, device=dev)
+        self.hidden = torch.zeros((n_songs, m.d_model), dtype=torch.float32, device=dev)
+        self.logits = torch.zeros((n_songs, m.n_logits), dtype=torch.float32, device=dev)
+        self.n_songs = n_songs
+
+    def step(self, tok):
+        from . import _lib
+        st = _lib.load().cwlt_decode_step(ctypes.byref(self.model), _lib.dev(tok), _lib.dev(self.work),
+                                          _lib.dev(self.hidden), _lib.dev(self.logits), self.n_songs,
+                                          _lib.stream_ptr())
+        _lib.check(st, "cwlt_decode_step")
+        return self.logits
+
+
+class DecodeSession:
+    """Decode state of `n_songs` songs + the captured one-token step.
+    `step(ids) -> (sum n_token,) f32 numpy logits` (or (n_songs, sum n_token) when n_songs > 1).
+
+    fused=True (default for f32 models): the step is `cwlt_decode_step` (csrc/decode.hip, 5 launches per layer);
+    fused=False: the layer-by-layer module path (recurrent.py), the only one for bf16 activations."""
+
+    def __init__(self, model, graph=None, fused=None, n_songs=1):
         if not getattr(model, "_recurrent", False):
             raise RuntimeError("generation needs a model built with is_training=False (recurrent encoder)")
         p = next(model.parameters())
@@ -38,32 +122,58 @@ class DecodeSession:
         self.model, self.dev = model, p.device
         self.n_token = list(model.n_token)
         self.width = sum(self.n_token)
+        self.n_songs = int(n_songs)
+        if fused is None:
+            fused = model.compute_dtype == torch.float32
+        if fused and model.compute_dtype != torch.float32:
+            raise RuntimeError("the fused decode step computes in f32; use fused=False for bf16 activations")
+        if not fused and self.n_songs != 1:
+            raise RuntimeError("the module-by-module decode path generates one song at a time (as the reference)")
+        self.fused = bool(fused)
         enc = model.transformer_encoder
         H = enc.layers[0].attention.n_heads
         d = model.d_model // H
-        self.tok = torch.zeros((1, 1, len(self.n_token)), dtype=torch.int64, device=self.dev)
-        self.memory = [[torch.zeros((1, H, d, d), dtype=torch.float32, device=self.dev),
-                        torch.zeros((1, H, d), dtype=torch.float32, device=self.dev)] for _ in enc.layers]
-        self._host_tok = torch.zeros((1, 1, len(self.n_token)), dtype=torch.int64).pin_memory()
-        self._host_logits = torch.zeros((self.width,), dtype=torch.float32).pin_memory()
+        n, A = self.n_songs, len(self.n_token)
+        self.tok = torch.zeros((n, 1, A), dtype=torch.int64, device=self.dev)
+        self.memory = [[torch.zeros((n, H, d, d), dtype=torch.float32, device=self.dev),
+                        torch.zeros((n, H, d), dtype=torch.float32, device=self.dev)] for _ in enc.layers]
+        self._host_tok = torch.zeros((n, 1, A), dtype=torch.int64).pin_memory()
+        self._host_logits = torch.zeros((n, self.width), dtype=torch.float32).pin_memory()
         self.use_graph = ops.GRAPHS_ENABLED if graph is None else bool(graph)
-        self._graph, self._out = None, None
+        self._graph, self._out, self._plan = None, None, None
+        self.hidden = None                                  # (n_songs, d_model) device tensor after a step
         self.n_steps = 0
 
+    def _weights_tag(self):
+        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+
     def reset(self):
+        """Start new songs: zero the state.  The packed weights and the captured graph are kept unless a parameter
+        changed since they were built (optimizer step, load_state_dict)."""
         for S, Z in self.memory:
             S.zero_()
             Z.zero_()
+        if self.fused and self._plan is not None and self._plan.tag != self._weights_tag():
+            self._plan, self._graph = None, None
         self.n_steps = 0
 
     def _device_step(self):
         """testing-no-type-cp.py:150 / :166 (`forward_hidden(input_, memory, is_training=False)`) followed by the six
         head projections of forward_output_sampling (dqn_policy/model.py:273-278) as one fused GEMV."""
+        if self.fused:
+            if self._plan is None:
+                with torch.no_grad():
+                    self._plan = _FusedPlan(self.model, self.memory, self.n_songs)
+                self._plan.tag = self._weights_tag()
+            out = self._plan.step(self.tok)
+            self.hidden = self._plan.hidden
+            return out
         h, mem = self.model.forward_hidden(self.tok, self.memory, is_training=False)
         for (S, Z), (S2, Z2) in zip(self.memory, mem):
             if S2.data_ptr() != S.data_ptr() or Z2.data_ptr() != Z.data_ptr():
                 raise RuntimeError("recurrent state must be updated in place")
-        return self.model.fused_logits(h).float()[0, :self.width].contiguous()
+        self.hidden = h
+        return self.model.fused_logits(h).float()[:, :self.width].contiguous()
 
     def _capture(self):
         saved = [(S.clone(), Z.clone()) for S, Z in self.memory]
@@ -83,7 +193,7 @@ class DecodeSession:
         self._graph, self._out = g, out
 
     def step(self, ids):
-        """Feed one CW token (6 ids), advance the state, return the next-token logits (host numpy, f32)."""
+        """Feed one CW token per song (6 ids each), advance the state, return the next-token logits (host numpy)."""
         if self.model.training:
             raise RuntimeError("generation runs in eval() mode (agent_pretrain.py:657)")
         self._host_tok.view(-1).copy_(torch.as_tensor(np.asarray(ids, dtype=np.int64).reshape(-1)))
@@ -99,12 +209,13 @@ class DecodeSession:
         self._host_logits.copy_(out, non_blocking=True)
         torch.cuda.current_stream(self.dev).synchronize()
         self.n_steps += 1
-        return self._host_logits.numpy()
+        res = self._host_logits.numpy()
+        return res[0] if self.n_songs == 1 else res
 
     def split(self, logits):
         outs, o = [], 0
         for n in self.n_token:
-            outs.append(logits[o:o + n])
+            outs.append(logits[..., o:o + n])
             o += n
         return outs
 

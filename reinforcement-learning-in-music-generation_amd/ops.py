@@ -767,3 +767,26 @@ def recurrent_cla_step(qkv, S, Z, H, eps=CLA_EPS):
 
 def sqrt_width(w):
     return math.sqrt(w)
+
+
+# --------------------------------------------------------------------------------------------------
+# generation: the decode step's GEMV building block (csrc/decode.hip); the whole step is generation.DecodeSession
+# --------------------------------------------------------------------------------------------------
+def decode_gemv(w, bias, x, ln=None, ln2=None, eps=1e-5, res=None, act=None, want_normed=False):
+    """out[n] = epi(W . pro(x[n]) + bias): pro = LayerNorm(*ln) then LayerNorm(*ln2) when given; epi = exact GELU when
+    act == "gelu", then + res[n].  x (n, K) f32, w (n_out, K) f32 -> (n, n_out) f32 [, the normalised x]."""
+    if x.dtype != torch.float32 or w.dtype != torch.float32:
+        raise TypeError("decode_gemv computes in f32")
+    n, K = x.shape
+    n_out = w.shape[0]
+    x, w = x.contiguous(), w.contiguous()
+    out = torch.empty((n, n_out), dtype=torch.float32, device=x.device)
+    xn = torch.empty_like(x) if (want_normed and ln is not None) else None
+    if res is not None:
+        res = res.contiguous()
+    p = lambda pair, i: _lib.opt(None if pair is None else pair[i].contiguous())
+    _call("cwlt_decode_gemv", _lib.dev(w, "w"), _lib.opt(bias), _lib.dev(x, "x"), p(ln, 0), p(ln, 1), p(ln2, 0),
+          p(ln2, 1), float(eps), _lib.opt(res), _lib.dev(out), _lib.opt(xn), n_out, K, 1 if act == "gelu" else 0, n,
+          K, n_out, n_out, K, _lib.stream_ptr())
+    return (out, xn) if want_normed else out
+

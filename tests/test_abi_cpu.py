@@ -21,7 +21,7 @@ def built():
 def _declared():
     text = open(os.path.join(ROOT, "include", "cwlt.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(cwlt_\w+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(?:int|int64_t)\s+(cwlt_\w+)\s*\(", text)))
 
 
 def test_header_symbols_are_exported(built):
@@ -49,6 +49,11 @@ def test_argument_validation_without_gpu(built):
     assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 0, null) == 1001
     assert lib.cwlt_add_dropout_layernorm_fwd(null, null, null, null, null, null, null, null, 4, 512, 1e-5, 0.0, 0, null, 0, null) == 1001
     assert lib.cwlt_ln_blocks(65536) == 1024 and lib.cwlt_ln_blocks(1) == 1
+    # generation step: an incomplete model description is refused before any launch
+    m = built.DecodeModel()
+    assert lib.cwlt_decode_workspace_floats(ctypes.byref(m)) == -1
+    assert lib.cwlt_decode_step(ctypes.byref(m), buf, buf, null, buf, 1, null) == 1001
+    assert lib.cwlt_decode_gemv(buf, null, buf, null, null, null, null, 1e-5, null, buf, null, 8, 6, 0, 1, 6, 8, 8, 6, null) == 1001
 
 
 def test_product_has_no_cpu_fallback(built):

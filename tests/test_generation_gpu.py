@@ -40,10 +40,35 @@ def _word2event():
     return w2e
 
 
-@pytest.mark.parametrize("graph", [False, True])
-def test_decode_session_matches_reference_stream(cuda, graph):
+def test_decode_gemv_building_block(cuda):
+    """csrc/decode.hip GEMV with LayerNorm prologue(s) and bias / GELU / residual epilogue vs torch f32."""
+    import torch.nn.functional as F
+    from rlmg_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for n, K, n_out in [(1, 512, 1536), (1, 512, 2048), (1, 2048, 512), (1, 1216, 512), (1, 512, 339), (3, 128, 384),
+                        (2, 128, 339), (1, 512, 1)]:
+        x = torch.randn(n, K, generator=g).to(cuda)
+        w = (torch.randn(n_out, K, generator=g) / K ** 0.5).to(cuda)
+        b = torch.randn(n_out, generator=g).to(cuda)
+        res = torch.randn(n, n_out, generator=g).to(cuda)
+        ln = (1 + 0.1 * torch.randn(K, generator=g)).to(cuda), (0.1 * torch.randn(K, generator=g)).to(cuda)
+        ln2 = (1 + 0.1 * torch.randn(K, generator=g)).to(cuda), (0.1 * torch.randn(K, generator=g)).to(cuda)
+        assert (ops.decode_gemv(w, b, x) - F.linear(x, w, b)).abs().max().item() < 2e-5
+        assert (ops.decode_gemv(w, None, x, res=res) - (F.linear(x, w) + res)).abs().max().item() < 2e-5
+        x1 = F.layer_norm(x, (K,), ln[0], ln[1], 1e-5)
+        got, xn = ops.decode_gemv(w, b, x, ln=ln, act="gelu", want_normed=True)
+        assert (xn - x1).abs().max().item() < 2e-5
+        assert (got - F.gelu(F.linear(x1, w, b))).abs().max().item() < 2e-5
+        x2 = F.layer_norm(x1, (K,), ln2[0], ln2[1], 1e-5)
+        got, xn = ops.decode_gemv(w, b, x, ln=ln, ln2=ln2, res=res, want_normed=True)
+        assert (xn - x2).abs().max().item() < 2e-5
+        assert (got - (F.linear(x2, w, b) + res)).abs().max().item() < 3e-5
+
+
+@pytest.mark.parametrize("graph,fused", [(False, False), (True, False), (False, True), (True, True)])
+def test_decode_session_matches_reference_stream(cuda, graph, fused):
     net = _small_model(cuda)
-    sess = generation.DecodeSession(net, graph=graph)
+    sess = generation.DecodeSession(net, graph=graph, fused=fused)
     # teacher forced: the recorded tokens in, the recorded logits out
     for t in range(len(FIX["logits"])):
         got = sess.step(FIX["tokens"][t])
@@ -75,6 +100,37 @@ def test_inference_from_scratch_and_generate(cuda, tmp_path):
     # max_tokens caps an otherwise unbounded song
     res = generation.inference_from_scratch(net, w2e, bar_cond=10 ** 6, max_tokens=20)
     assert len(res) == 20
+
+
+def test_fused_decode_batch_of_songs_and_weight_reload(cuda):
+    """n_songs > 1: each song's state is its own (song i == a single-song session fed song i's tokens); the packed
+    weights follow the model's parameters across reset()."""
+    net = _small_model(cuda)
+    g = torch.Generator().manual_seed(9)
+    toks = torch.stack([torch.randint(0, n, (3, 12), generator=g) for n in N_CLASS], -1).numpy()    # (3, 12, 6)
+    batch = generation.DecodeSession(net, n_songs=3)
+    got = np.stack([batch.step(toks[:, t]).copy() for t in range(12)], 1)                            # (3, 12, W)
+    assert batch.hidden.shape == (3, 128)
+    single = generation.DecodeSession(net)
+    for i in range(3):
+        single.reset()
+        for t in range(12):
+            assert np.abs(single.step(toks[i, t]) - got[i, t]).max() < 1e-5, (i, t)
+    # the hidden row is what the module path's forward_hidden returns
+    ref = generation.DecodeSession(net, fused=False, graph=False)
+    single.reset()
+    for t in range(12):
+        a, b = single.step(toks[0, t]).copy(), ref.step(toks[0, t]).copy()
+        assert np.abs(a - b).max() < 1e-4
+        assert (single.hidden.view(-1) - ref.hidden.view(-1)).abs().max().item() < 1e-4
+    # new weights are picked up at the next reset()
+    with torch.no_grad():
+        net.proj_pitch.bias.add_(1.0)
+    single.reset()
+    o = sum(N_CLASS[:3])
+    after = single.step(toks[0, 0]).copy()
+    assert np.abs((after - got[0, 0])[o:o + N_CLASS[3]] - 1.0).max() < 1e-5
+    assert np.abs(np.delete(after - got[0, 0], np.s_[o:o + N_CLASS[3]])).max() < 1e-5
 
 
 def test_generation_refuses_training_form_and_train_mode(cuda):

@@ -29,8 +29,9 @@ def main():
     net = model.LinearTransformer(n_class, is_training=False).cuda().eval()
     if a.dtype == "bf16":
         net.compute_dtype = torch.bfloat16
-    for graph in ([False] if a.no_graph else [False, True]):
-        sess = generation.DecodeSession(net, graph=graph)
+    modes = [(g, f) for f in ([False, True] if a.dtype == "f32" else [False]) for g in ([False] if a.no_graph else [False, True])]
+    for graph, fused in modes:
+        sess = generation.DecodeSession(net, graph=graph, fused=fused)
         np.random.seed(0)
         tok = generation.INIT_CW[0]
         for _ in range(8):
@@ -43,7 +44,7 @@ def main():
         for _ in range(a.tokens):
             sess.step(tok)
         t2 = time.perf_counter()
-        print(json.dumps({"metric": "decode CW-tokens/s (1 song)", "graph": graph, "dtype": a.dtype,
+        print(json.dumps({"metric": "decode CW-tokens/s (1 song)", "graph": graph, "fused": fused, "dtype": a.dtype,
                           "with_sampling": round(a.tokens / (t1 - t0), 1),
                           "device_only": round(a.tokens / (t2 - t1), 1),
                           "us_per_token_device": round((t2 - t1) / a.tokens * 1e6, 1)}), flush=True)
