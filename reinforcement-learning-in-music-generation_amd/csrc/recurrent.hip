@@ -8,55 +8,54 @@
 // q, k, v: (N, H, 64) rows of the per-token projections (row stride ld*); S: (N, H, 64, 64) f32 and
 // Z: (N, H, 64) f32 are updated IN PLACE.  One workgroup (256 threads) per (n, h): thread (d-quarter, m)
 // owns 16 rows of one state column, so the 16 KiB state streams through registers exactly once
-// (read + write = 32 KiB per head per token: the step is pure HBM/L2 traffic, launch-latency bound).
+// (read + write = 32 KiB per head per token: the step is pure HBM/L2 traffic, launch-latency bound --
+// hence one memory round trip and one barrier, see the kernel).
 #include "cwlt_common.h"
 
 namespace cwlt {
+
+__device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : (expf(x) - 1.f) + 1.f; }
 
 template <typename T>
 __global__ __launch_bounds__(256) void recurrent_cla_step_kernel(const T* __restrict__ q, const T* __restrict__ k,
                                                                  const T* __restrict__ v, float* __restrict__ S,
                                                                  float* __restrict__ Z, T* __restrict__ out, int H,
                                                                  long ldq, long ldk, long ldv, long ldo, float eps) {
-    __shared__ float qf[64], kf[64], vv[64], part[4][64], den_s;
-    const int tid = threadIdx.x;
+    // Wave w owns state rows 16w .. 16w+15, lane m owns column m.  Every load a thread needs (q, k, v, Z and its 16
+    // state values) is independent of every other and issued up front: one memory round trip, then registers.
+    // phi(q)[d], phi(k)[d] for the wave's 16 rows come out of the wave's own lane-indexed copy with v_readlane
+    // (d is wave-uniform) -- no LDS staging, ONE barrier (to add the four row-quarter partial sums).
+    __shared__ float part[4][64];
+    __shared__ float den_s;
+    const int lane = threadIdx.x & 63, w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int n = blockIdx.x / H, h = blockIdx.x % H;
-    if (tid < 64) {
-        const float x = load1(q + (long)n * ldq + h * 64 + tid);
-        qf[tid] = x > 0.f ? x + 1.f : (expf(x) - 1.f) + 1.f;
-    } else if (tid < 128) {
-        const int d = tid - 64;
-        const float x = load1(k + (long)n * ldk + h * 64 + d);
-        kf[d] = x > 0.f ? x + 1.f : (expf(x) - 1.f) + 1.f;
-    } else if (tid < 192) {
-        vv[tid - 128] = load1(v + (long)n * ldv + h * 64 + (tid - 128));
-    }
-    __syncthreads();
+    float* Sb = S + ((long)n * H + h) * 4096 + (w * 16) * 64 + lane;
     float* Zb = Z + ((long)n * H + h) * 64;
-    if (tid < 64) {
-        const float z = Zb[tid] + kf[tid];
-        Zb[tid] = z;
-        float d = qf[tid] * z;
-        d = wave_sum(d);
-        if (tid == 0) den_s = d;
+    float s[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s[i] = Sb[i * 64];
+    const float qf = phi(load1(q + (long)n * ldq + h * 64 + lane));
+    const float kf = phi(load1(k + (long)n * ldk + h * 64 + lane));
+    const float vm = load1(v + (long)n * ldv + h * 64 + lane);
+    if (w == 0) {                                   // normaliser: only wave 0 touches Z
+        const float z = Zb[lane] + kf;
+        Zb[lane] = z;
+        const float d = wave_sum(qf * z);
+        if (lane == 0) den_s = d;
     }
-    // state column m, rows d0 .. d0+15
-    const int m = tid & 63, d0 = (tid >> 6) * 16;
-    float* Sb = S + ((long)n * H + h) * 4096;
     float acc = 0.f;
-    const float vm = vv[m];
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
-        const int d = d0 + i;
-        const float s = fmaf(kf[d], vm, Sb[d * 64 + m]);
-        Sb[d * 64 + m] = s;
-        acc = fmaf(qf[d], s, acc);
+        const float kd = lane_value(kf, w * 16 + i), qd = lane_value(qf, w * 16 + i);
+        s[i] = fmaf(kd, vm, s[i]);
+        Sb[i * 64] = s[i];
+        acc = fmaf(qd, s[i], acc);
     }
-    part[tid >> 6][m] = acc;
+    part[w][lane] = acc;
     __syncthreads();
-    if (tid < 64) {
-        const float num = (part[0][tid] + part[1][tid]) + (part[2][tid] + part[3][tid]);
-        store1(out + (long)n * ldo + h * 64 + tid, num * (1.0f / (den_s + eps)));
+    if (w == 0) {
+        const float num = (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+        store1(out + (long)n * ldo + h * 64 + lane, num * (1.0f / (den_s + eps)));
     }
 }
 

@@ -27,6 +27,24 @@ def _synth(n_seq, T, n_per_field, seed):
     return x, y, mask
 
 
+def synthetic_cp_vocabulary():
+    """word2event of the same shape as the compound-word dictionary the reference trains on (class counts of
+    IRL_dqn_train.py:403; event spellings as dqn_policy/testing-no-type-cp.py:56-117 parses them: 0 = ignore,
+    'CONTI', 'Bar', 'Beat_<k>', 'Tempo_<bpm>', 'Note_Pitch_<p>', 'Note_Duration_<ticks>', 'Note_Velocity_<v>')."""
+    tempo = [0, "CONTI"] + ["Tempo_%d" % (32 + 3 * i) for i in range(DQN_N[0] - 2)]
+    roots = ["C", "C#", "D", "D#", "E", "F", "F#", "G", "G#", "A", "A#", "B"]
+    quals = ["M", "m", "o", "+", "7", "M7", "m7", "o7", "/o7", "sus2", "sus4"]
+    chord = ([0, "CONTI"] + ["%s_%s" % (r, q) for r in roots for q in quals] + ["N_N"])[:DQN_N[1]]
+    barbeat = [0, "Bar"] + ["Beat_%d" % i for i in range(DQN_N[2] - 2)]
+    typ = ["EOS", "Metrical", "Note"]
+    pitch = [0] + ["Note_Pitch_%d" % (22 + i) for i in range(DQN_N[4] - 1)]
+    duration = [0] + ["Note_Duration_%d" % (120 * (i + 1)) for i in range(DQN_N[5] - 1)]
+    velocity = [0] + ["Note_Velocity_%d" % (40 + 2 * i) for i in range(DQN_N[6] - 1)]
+    cols = (tempo, chord, barbeat, typ, pitch, duration, velocity)
+    assert tuple(len(c) for c in cols) == DQN_N
+    return {k: dict(enumerate(c)) for k, c in zip(DQN_KEYS, cols)}
+
+
 def load_dqn(path_train_data, path_dictionary, n_seq=8, T=3584, seed=1234):
     """-> (event2word, word2event), {x, y, mask}; synthetic when the files are absent."""
     if os.path.exists(path_train_data) and os.path.exists(path_dictionary):
@@ -35,8 +53,8 @@ def load_dqn(path_train_data, path_dictionary, n_seq=8, T=3584, seed=1234):
         d = np.load(path_train_data)
         return dictionary, {"x": d["x"], "y": d["y"], "mask": d["mask"]}
     print("[data] %s not found: using synthetic CW tokens of the same schema" % path_train_data)
-    e2w = {k: {"%s_%d" % (k, i): i for i in range(n)} for k, n in zip(DQN_KEYS, DQN_N)}
-    w2e = {k: {i: e for e, i in v.items()} for k, v in e2w.items()}
+    w2e = synthetic_cp_vocabulary()
+    e2w = {k: {e: i for i, e in v.items()} for k, v in w2e.items()}
     x, y, mask = _synth(n_seq, T, DQN_N, seed)
     return (e2w, w2e), {"x": x, "y": y, "mask": mask}
 

@@ -1,6 +1,6 @@
-"""Drop-in for /root/reference/dqn_policy/agent_pretrain.py (MODE='train'): `TransformerModel`
-(the same network as model.LinearTransformer) and `train()`.  `generate()` / `write_midi` (MIDI output,
-needs miditoolkit) are outside the hot path -- SURVEY §2a marks them OUT OF SCOPE.
+"""Drop-in for /root/reference/dqn_policy/agent_pretrain.py: `TransformerModel` (the same network as
+model.LinearTransformer), `train()` (MODE='train') and `generate()` (MODE='inference': token-by-token sampling on
+the recurrent form, rlmg_amd.generation; songs are written with rlmg_amd.midi.write_midi).
 """
 import datetime
 import os
@@ -97,8 +97,31 @@ def train(n_epoch=None, compute_dtype=torch.float32, log=print):
     return epoch_loss
 
 
-def generate():
-    raise NotImplementedError("generation / MIDI writing is outside the training hot path (SURVEY §2a, §8f #1)")
+path_gendir = "gen_midis"
+num_songs = 5
+bar_production = 50                               # testing-no-type-cp.py:35
+
+
+def generate(n_songs=None, bar_cond=None, max_tokens=None, log=print):
+    """agent_pretrain.py:636-706 / testing-no-type-cp.py:182-260: build the recurrent-form net, load
+    ./ckpt/_params.pt when present, sample `num_songs` songs, write get_<i>.mid + runtime_stats.json."""
+    from rlmg_amd import generation, midi
+    dictionary, _ = cwdata.load_dqn(path_train_data, path_dictionary, n_seq=1, T=64)
+    event2word, word2event = ({k: v for k, v in d.items() if k != "type"} for d in dictionary)
+    n_class = [len(event2word[k]) for k in event2word.keys()]
+    net = TransformerModel(n_class, is_training=False)
+    net.cuda()
+    net.eval()
+    path_saved_ckpt = os.path.join("./ckpt/" + "_params.pt")
+    if os.path.exists(path_saved_ckpt):
+        log("[*] load model from:", path_saved_ckpt)
+        sd = torch.load(path_saved_ckpt)
+        net.load_state_dict(sd.get("model_state_dict", sd))
+    else:
+        log("[*] %s not found: sampling from freshly initialised weights" % path_saved_ckpt)
+    return generation.generate(net, word2event, n_songs=num_songs if n_songs is None else n_songs,
+                               bar_cond=bar_production if bar_cond is None else bar_cond, path_gendir=path_gendir,
+                               write_midi=midi.write_midi, max_tokens=max_tokens, log=log)
 
 
 if __name__ == "__main__":

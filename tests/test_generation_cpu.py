@@ -50,3 +50,33 @@ def test_oracle_recurrent_generation_matches_fixture():
             assert np.abs(np.concatenate(ys) - FIX["logits"][t]).max() < 1e-5
             tok = sample_cw(ys)
             assert tok.tolist() == FIX["tokens"][t + 1].tolist(), t
+
+
+def test_words_to_midi_events_and_smf_round_trip(tmp_path):
+    """midi.write_midi: token semantics of the reference's writer (testing-no-type-cp.py:56-123) on a hand-made
+    song, and the SMF bytes parse back to the same events."""
+    from rlmg_amd import data, midi
+    w2e = {k: v for k, v in data.synthetic_cp_vocabulary().items() if k != "type"}
+    e2w = {k: {e: i for i, e in v.items()} for k, v in w2e.items()}
+    assert [len(w2e[k]) for k in w2e] == [56, 135, 18, 87, 18, 25]
+
+    def metrical(tempo, chord, bb):
+        return [e2w["tempo"][tempo], e2w["chord"][chord], e2w["bar-beat"][bb], 0, 0, 0]
+
+    def note(p, d, v):
+        return [0, 0, 0, e2w["pitch"]["Note_Pitch_%d" % p], e2w["duration"]["Note_Duration_%d" % d],
+                e2w["velocity"]["Note_Velocity_%d" % v]]
+
+    words = np.array([metrical(0, 0, "Bar"), metrical("Tempo_110", "C_M", "Beat_0"), note(60, 480, 64),
+                      note(64, 240, 70), metrical("CONTI", "CONTI", "Beat_4"), note(67, 120, 80),
+                      metrical(0, 0, "Bar"), metrical("CONTI", "G_7", "Beat_8"), note(55, 960, 50)])
+    ev = midi.write_midi(words, str(tmp_path / "a.mid"), w2e)
+    # Bar increments BEFORE the first beat, so bar 1 starts at tick 1920 (the reference's convention)
+    assert ev["tempo_changes"] == [(1920, 110)]
+    assert ev["markers"] == [(1920, "C_M"), (2 * 1920 + 8 * 120, "G_7")]
+    assert ev["notes"] == [(60, 1920, 2400, 64), (64, 1920, 2160, 70), (67, 1920 + 480, 1920 + 600, 80),
+                           (55, 2 * 1920 + 960, 2 * 1920 + 1920, 50)]
+    back = midi.read_smf(str(tmp_path / "a.mid"))
+    assert back["ticks_per_beat"] == 480
+    assert back["notes"] == sorted(ev["notes"], key=lambda x: (x[1], x[0]))
+    assert back["markers"] == ev["markers"] and back["tempo_changes"] == ev["tempo_changes"]

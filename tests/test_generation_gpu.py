@@ -146,3 +146,24 @@ def test_generation_refuses_training_form_and_train_mode(cuda):
     net = _small_model(cuda).train()
     with pytest.raises(RuntimeError):
         generation.DecodeSession(net).step(FIX["tokens"][0])
+
+
+def test_agent_pretrain_generate_writes_midis(cuda, tmp_path, monkeypatch):
+    """agent_pretrain.generate() (MODE='inference'): recurrent-form net -> sampled songs -> get_<i>.mid that parse
+    back, + runtime_stats.json."""
+    from rlmg_amd import midi
+    from rlmg_amd.dqn_policy import agent_pretrain, config
+    monkeypatch.chdir(tmp_path)
+    old = dict(config.AgentConfig)
+    config.AgentConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    try:
+        torch.manual_seed(0)
+        np.random.seed(0)
+        stats = agent_pretrain.generate(n_songs=2, bar_cond=4, max_tokens=300, log=lambda *a: None)
+    finally:
+        config.AgentConfig.update(old)
+    assert len(stats["words_len_list"]) == 2 and all(2 <= n <= 300 for n in stats["words_len_list"])
+    for i in range(2):
+        song = midi.read_smf(str(tmp_path / "gen_midis" / ("get_%d.mid" % i)))
+        assert song["ticks_per_beat"] == 480
+    assert os.path.exists(tmp_path / "runtime_stats.json")
