@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--tokens", type=int, default=512)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--dtype", default="f32")
+    ap.add_argument("--songs", type=int, nargs="*", default=[8, 32], help="extra batched-songs runs (device only)")
     a = ap.parse_args()
     from rlmg_amd.dqn_policy import model
     n_class = [56, 135, 18, 87, 18, 25]
@@ -48,6 +49,20 @@ def main():
                           "with_sampling": round(a.tokens / (t1 - t0), 1),
                           "device_only": round(a.tokens / (t2 - t1), 1),
                           "us_per_token_device": round((t2 - t1) / a.tokens * 1e6, 1)}), flush=True)
+    if a.dtype == "f32":
+        for n in a.songs:
+            sess = generation.DecodeSession(net, graph=True, fused=True, n_songs=n)
+            tok = np.tile(generation.INIT_CW[0], (n, 1))
+            for _ in range(8):
+                sess.step(tok)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(a.tokens):
+                sess.step(tok)
+            t1 = time.perf_counter()
+            print(json.dumps({"metric": "decode CW-tokens/s (%d songs in lock-step)" % n, "graph": True, "fused": True,
+                              "device_only": round(n * a.tokens / (t1 - t0), 1),
+                              "us_per_step_device": round((t1 - t0) / a.tokens * 1e6, 1)}), flush=True)
 
 
 if __name__ == "__main__":
