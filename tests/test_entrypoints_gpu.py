@@ -166,6 +166,12 @@ def test_agent_pretrain_train_short_run(cuda, tmp_path, monkeypatch):
         loss = A.train(n_epoch=2, log=lambda *a: None)
         assert loss == loss and 0 < loss < 10
         assert any(f.startswith("trainloss_") for f in os.listdir("ckpt"))
+        # exp/log.txt in the reference's Saver format: 2 epochs x 2 batches of 4 + epoch lines
+        lines = open(os.path.join("exp", "log.txt")).read().splitlines()
+        assert sum(l.startswith("batch loss") for l in lines) == 4
+        assert sum(l.startswith("epoch loss") for l in lines) == 2
+        key, val, step, _ = [l for l in lines if l.startswith("epoch loss")][-1].split(" | ")
+        assert abs(float(val) - loss) < 1e-9 and int(step) == 4
     finally:
         config.AgentConfig.update(old)
 

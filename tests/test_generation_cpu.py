@@ -80,3 +80,22 @@ def test_words_to_midi_events_and_smf_round_trip(tmp_path):
     assert back["ticks_per_beat"] == 480
     assert back["notes"] == sorted(ev["notes"], key=lambda x: (x[1], x[0]))
     assert back["markers"] == ev["markers"] and back["tempo_changes"] == ev["tempo_changes"]
+
+
+def test_saver_log_format(tmp_path):
+    """dqn_policy/saving.py::Saver writes the reference's log.txt lines (saving.py:36-64): 'key | val | step | time',
+    floats with 10 decimals, key padded to 10 -- and the reference's own parser (split on ' | ') reads them back."""
+    from rlmg_amd.dqn_policy.saving import Saver
+    s = Saver(str(tmp_path / "exp"))
+    s.add_summary_msg(" > params amount: 38,982,227")
+    s.global_step_increment()
+    s.add_summary("batch loss", 1.25)
+    s.add_summary("epoch each loss", "1.0, 2.0")
+    s.add_summary("lr", 3, step=7, cur_time=0.5)
+    s.close()
+    lines = open(tmp_path / "exp" / "log.txt").read().splitlines()
+    assert lines[0] == " > params amount: 38,982,227"
+    key, val, step, t = lines[1].split(" | ")
+    assert key == "batch loss" and val == "1.2500000000" and step == "         1" and float(t) >= 0
+    assert lines[2].startswith("epoch each loss | 1.0, 2.0 |          1 | ")
+    assert lines[3] == "lr         | 3 |          7 | 0.5"
