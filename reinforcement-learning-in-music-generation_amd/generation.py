@@ -135,8 +135,11 @@ class DecodeSession:
         d = model.d_model // H
         n, A = self.n_songs, len(self.n_token)
         self.tok = torch.zeros((n, 1, A), dtype=torch.int64, device=self.dev)
-        self.memory = [[torch.zeros((n, H, d, d), dtype=torch.float32, device=self.dev),
-                        torch.zeros((n, H, d), dtype=torch.float32, device=self.dev)] for _ in enc.layers]
+        per = n * H * d * (d + 1)                           # all layers' [S, Zs] in ONE buffer: reset = one memset
+        self._state = torch.zeros(per * len(enc.layers), dtype=torch.float32, device=self.dev)
+        self.memory = [[self._state[i * per:i * per + n * H * d * d].view(n, H, d, d),
+                        self._state[i * per + n * H * d * d:(i + 1) * per].view(n, H, d)]
+                       for i in range(len(enc.layers))]
         self._host_tok = torch.zeros((n, 1, A), dtype=torch.int64).pin_memory()
         self._host_logits = torch.zeros((n, self.width), dtype=torch.float32).pin_memory()
         self.use_graph = ops.GRAPHS_ENABLED if graph is None else bool(graph)
@@ -150,9 +153,7 @@ class DecodeSession:
     def reset(self):
         """Start new songs: zero the state.  The packed weights and the captured graph are kept unless a parameter
         changed since they were built (optimizer step, load_state_dict)."""
-        for S, Z in self.memory:
-            S.zero_()
-            Z.zero_()
+        self._state.zero_()
         if self.fused and self._plan is not None and self._plan.tag != self._weights_tag():
             self._plan, self._graph = None, None
         self.n_steps = 0
@@ -176,7 +177,7 @@ class DecodeSession:
         return self.model.fused_logits(h).float()[:, :self.width].contiguous()
 
     def _capture(self):
-        saved = [(S.clone(), Z.clone()) for S, Z in self.memory]
+        saved = self._state.clone()
         side = torch.cuda.Stream(device=self.dev)
         side.wait_stream(torch.cuda.current_stream(self.dev))
         with torch.cuda.stream(side), torch.no_grad():
@@ -187,9 +188,7 @@ class DecodeSession:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g), torch.no_grad():
             out = self._device_step()
-        for (S, Z), (S0, Z0) in zip(self.memory, saved):      # warm-up and capture ran the step: restore
-            S.copy_(S0)
-            Z.copy_(Z0)
+        self._state.copy_(saved)                              # warm-up and capture ran the step: restore
         self._graph, self._out = g, out
 
     def step(self, ids):
@@ -218,6 +217,51 @@ class DecodeSession:
             outs.append(logits[..., o:o + n])
             o += n
         return outs
+
+
+def categorical_rollout(model, token_count, init=None, carry_memory=False, graph=None):
+    """ppo_policy/inference.py:78-160 (`testing()`): start from the all-zero token, per step run the recurrent-form
+    actor on the PREVIOUS token only -- the reference passes `memory=None` on every call (:106), so no state is
+    carried; `carry_memory=True` is the evident intent -- and draw each attribute from Categorical(softmax(logits))
+    (:121-133).  Everything stays on the device: decode step, six softmax + multinomial draws (torch's device
+    generator, as the reference's torch.distributions), token fed back; ONE host sync at the end.
+    -> (token_count, 6) int64 numpy."""
+    sess = DecodeSession(model, graph=False)
+    if sess.model.training:
+        raise RuntimeError("generation runs in eval() mode (ppo_policy/inference.py:96)")
+    A = len(sess.n_token)
+    song = torch.zeros((token_count, A), dtype=torch.int64, device=sess.dev)
+    count = torch.zeros(1, dtype=torch.int64, device=sess.dev)
+    sess.tok.copy_(torch.as_tensor(np.zeros(A) if init is None else np.asarray(init), dtype=torch.int64)
+                   .view(1, 1, A).to(sess.dev))
+
+    def one_token():
+        if not carry_memory:
+            sess._state.zero_()
+        logits = sess._device_step()
+        o = 0
+        for a, n in enumerate(sess.n_token):
+            probs = torch.softmax(logits[0, o:o + n], dim=-1)
+            sess.tok[0, 0, a:a + 1] = torch.multinomial(probs, 1)
+            o += n
+        song.index_copy_(0, count, sess.tok.view(1, A))
+        count.add_(1)
+
+    use_graph = ops.GRAPHS_ENABLED if graph is None else bool(graph)
+    with torch.no_grad():
+        if use_graph and token_count > 4:
+            one_token()
+            one_token()                                   # warm-up (real tokens 0 and 1), then capture token 2
+            torch.cuda.synchronize(sess.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                one_token()
+            for _ in range(token_count - 3):
+                g.replay()
+        else:
+            for _ in range(token_count):
+                one_token()
+    return song.cpu().numpy()
 
 
 def inference_from_scratch(model, word2event, bar_cond, max_tokens=None, log=None, session=None):

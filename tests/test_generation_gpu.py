@@ -167,3 +167,39 @@ def test_agent_pretrain_generate_writes_midis(cuda, tmp_path, monkeypatch):
         song = midi.read_smf(str(tmp_path / "gen_midis" / ("get_%d.mid" % i)))
         assert song["ticks_per_beat"] == 480
     assert os.path.exists(tmp_path / "runtime_stats.json")
+
+
+def test_ppo_categorical_rollout(cuda, tmp_path, monkeypatch):
+    """ppo_policy/inference.py::testing: device-side Categorical sampling; with memory=None per call (the
+    reference's quirk) token t+1 depends on token t only, through the fresh-state logits."""
+    from rlmg_amd.ppo_policy import config, inference, model
+    monkeypatch.chdir(tmp_path)
+    old = dict(config.ActorConfig)
+    config.ActorConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    try:
+        n_token = [49, 19, 19, 89, 67, 25]
+        net = fill_params(model.Actor_Transformer(n_token, is_training=False), seed=3).to(cuda).eval()
+        torch.manual_seed(7)
+        a = generation.categorical_rollout(net, 40, graph=True)
+        torch.manual_seed(7)
+        b = generation.categorical_rollout(net, 40, graph=False)
+        assert a.shape == (40, 6) and all((a[:, i] < n).all() and (a[:, i] >= 0).all() for i, n in enumerate(n_token))
+        assert (a[:3] == b[:3]).all()                      # same generator state => same first draws in both modes
+        # every drawn id has non-negligible probability under the fresh-state logits of the previous token
+        sess = generation.DecodeSession(net, graph=False)
+        prev = np.zeros(6, dtype=np.int64)
+        for t in range(40):
+            sess.reset()
+            ys = sess.split(sess.step(prev).copy())
+            for i, y in enumerate(ys):
+                p = np.exp(y - y.max())
+                assert p[b[t, i]] / p.sum() > 1e-6
+            prev = b[t]
+        # carry_memory=True carries the state (differs from the quirk path after the first tokens)
+        torch.manual_seed(7)
+        c = generation.categorical_rollout(net, 40, carry_memory=True, graph=False)
+        assert (c[0] == b[0]).all() and c.shape == (40, 6)
+        song = inference.testing(token_count=12, log=lambda *a: None)
+        assert song.shape == (12, 6) and os.path.exists(tmp_path / "gen_midi" / "ppo_song.npy")
+    finally:
+        config.ActorConfig.update(old)
