@@ -251,16 +251,18 @@ def categorical_rollout(model, token_count, init=None, carry_memory=False, graph
     with torch.no_grad():
         if use_graph and token_count > 4:
             one_token()
-            one_token()                                   # warm-up (real tokens 0 and 1), then capture token 2
+            one_token()                                   # warm-up = the real tokens 0 and 1
             torch.cuda.synchronize(sess.dev)
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            with torch.cuda.graph(g):                     # recorded, not executed
                 one_token()
-            for _ in range(token_count - 3):
+            for _ in range(token_count - 2):
                 g.replay()
         else:
             for _ in range(token_count):
                 one_token()
+    if int(count.item()) != token_count:
+        raise RuntimeError("categorical_rollout produced %d of %d tokens" % (int(count.item()), token_count))
     return song.cpu().numpy()
 
 

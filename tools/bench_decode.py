@@ -50,6 +50,16 @@ def main():
                           "device_only": round(a.tokens / (t2 - t1), 1),
                           "us_per_token_device": round((t2 - t1) / a.tokens * 1e6, 1)}), flush=True)
     if a.dtype == "f32":
+        # device-resident loop (ppo_policy/inference.py style): Categorical draws on the GPU, one host sync per song
+        n_tok = 8 * a.tokens
+        generation.categorical_rollout(net, 16, carry_memory=True, graph=True)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        generation.categorical_rollout(net, n_tok, carry_memory=True, graph=True)
+        t1 = time.perf_counter()
+        print(json.dumps({"metric": "decode CW-tokens/s (1 song, sampling on the device)", "graph": True, "fused": True,
+                          "tokens": n_tok, "with_sampling": round(n_tok / (t1 - t0), 1),
+                          "us_per_token": round((t1 - t0) / n_tok * 1e6, 1)}), flush=True)
         for n in a.songs:
             sess = generation.DecodeSession(net, graph=True, fused=True, n_songs=n)
             tok = np.tile(generation.INIT_CW[0], (n, 1))
