@@ -285,6 +285,17 @@ int cwlt_decode_gemv(const float* W, const float* bias, const float* xin, const 
                      const float* res, float* out, float* x_out, int n_out, int K, int act, int n_songs,
                      int64_t ld_x, int64_t ld_res, int64_t ld_out, int64_t ld_xo, void* stream);
 
+/* Device-side sampling of the next CW token: for each of `rows` songs and each attribute a, draw from
+ * Categorical(softmax(logits[row, off_a : off_a + n_class[a]] / temperature[a])) and store the class id in
+ * tokens[row, a] (and in song[counter, row, a] when song != NULL and *counter < song_rows).  Replaces the six
+ * `Categorical(softmax(y)).sample()` draws + torch.cat of ppo_policy/inference.py:115-141 (same distribution; the
+ * generator is counter-based, keyed by (seed, *counter, row, a), so a captured graph draws fresh numbers per replay
+ * as long as the caller advances *counter).  n_class / temperature: HOST arrays (temperature NULL = 1.0);
+ * n_class[a] <= 256, n_attr <= 8; counter: device int64 (NULL = 0). */
+int cwlt_sample_categorical(const float* logits, const int* n_class, const float* temperature, int n_attr,
+                            int64_t rows, int64_t ld, uint64_t seed, const int64_t* counter, int64_t* tokens,
+                            int64_t* song, int64_t song_rows, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -223,8 +223,9 @@ def categorical_rollout(model, token_count, init=None, carry_memory=False, graph
     """ppo_policy/inference.py:78-160 (`testing()`): start from the all-zero token, per step run the recurrent-form
     actor on the PREVIOUS token only -- the reference passes `memory=None` on every call (:106), so no state is
     carried; `carry_memory=True` is the evident intent -- and draw each attribute from Categorical(softmax(logits))
-    (:121-133).  Everything stays on the device: decode step, six softmax + multinomial draws (torch's device
-    generator, as the reference's torch.distributions), token fed back; ONE host sync at the end.
+    (:121-133).  Everything stays on the device: decode step, then ONE sampling kernel (csrc/sample.hip: softmax +
+    inverse-CDF draw per attribute, written straight into the token buffer and the song), token fed back; ONE host
+    sync at the end.  Same distribution as the reference's torch.distributions draws, not the same random stream.
     -> (token_count, 6) int64 numpy."""
     sess = DecodeSession(model, graph=False)
     if sess.model.training:
@@ -235,16 +236,15 @@ def categorical_rollout(model, token_count, init=None, carry_memory=False, graph
     sess.tok.copy_(torch.as_tensor(np.zeros(A) if init is None else np.asarray(init), dtype=torch.int64)
                    .view(1, 1, A).to(sess.dev))
 
+    seed = ops.next_seed()                                # keyed from torch.manual_seed, like the dropout seeds
+    n_class = list(sess.n_token)
+    song3 = song.view(token_count, 1, A)
+
     def one_token():
         if not carry_memory:
             sess._state.zero_()
         logits = sess._device_step()
-        o = 0
-        for a, n in enumerate(sess.n_token):
-            probs = torch.softmax(logits[0, o:o + n], dim=-1)
-            sess.tok[0, 0, a:a + 1] = torch.multinomial(probs, 1)
-            o += n
-        song.index_copy_(0, count, sess.tok.view(1, A))
+        ops.sample_categorical(logits, n_class, sess.tok.view(1, A), seed, counter=count, song=song3)
         count.add_(1)
 
     use_graph = ops.GRAPHS_ENABLED if graph is None else bool(graph)

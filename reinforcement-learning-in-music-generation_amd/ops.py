@@ -2,6 +2,7 @@
 
 Everything here runs on the GPU through the C-ABI in include/cwlt.h; there is no CPU path.
 """
+import ctypes
 import math
 import os
 
@@ -789,4 +790,22 @@ def decode_gemv(w, bias, x, ln=None, ln2=None, eps=1e-5, res=None, act=None, wan
           p(ln2, 1), float(eps), _lib.opt(res), _lib.dev(out), _lib.opt(xn), n_out, K, 1 if act == "gelu" else 0, n,
           K, n_out, n_out, K, _lib.stream_ptr())
     return (out, xn) if want_normed else out
+
+
+def sample_categorical(logits, n_class, tokens, seed, counter=None, song=None, temperature=None):
+    """tokens[row, a] ~ Categorical(softmax(logits[row, segment a] / temperature[a])) on the device
+    (csrc/sample.hip; ppo_policy/inference.py:115-141).  logits (rows, >= sum n_class) f32; tokens (rows, A) int64
+    written in place; counter: device int64 scalar tensor that keys the draw (and indexes `song` (T, rows, A))."""
+    if logits.dtype != torch.float32 or tokens.dtype != torch.int64:
+        raise TypeError("sample_categorical takes f32 logits and int64 tokens")
+    rows, A = logits.shape[0], len(n_class)
+    if tokens.numel() != rows * A or not tokens.is_contiguous():
+        raise ValueError("tokens must be a contiguous (rows, n_attr) buffer")
+    if logits.stride(-1) != 1:
+        logits = logits.contiguous()
+    temp = None if temperature is None else (ctypes.c_float * A)(*[float(t) for t in temperature])
+    _call("cwlt_sample_categorical", _lib.dev(logits, "logits"), _lib.int_array(n_class), temp, A, rows,
+          logits.stride(0), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.opt(counter), _lib.dev(tokens, "tokens"), _lib.opt(song),
+          0 if song is None else song.shape[0], _lib.stream_ptr())
+    return tokens
 
