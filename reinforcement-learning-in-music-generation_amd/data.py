@@ -14,7 +14,7 @@ import numpy as np
 
 DQN_KEYS = ("tempo", "chord", "bar-beat", "type", "pitch", "duration", "velocity")
 DQN_N = (56, 135, 18, 3, 87, 18, 25)             # IRL_dqn_train.py:403 (+ 3 `type` classes)
-PPO_KEYS = ("tempo", "bar", "position", "pitch", "duration", "velocity")
+PPO_KEYS = ("Tempo", "Bar", "Position", "Pitch", "Duration", "Velocity")
 PPO_N = (49, 19, 19, 89, 67, 25)                 # prepare_data.py:247-291
 
 
@@ -59,6 +59,21 @@ def load_dqn(path_train_data, path_dictionary, n_seq=8, T=3584, seed=1234):
     return (e2w, w2e), {"x": x, "y": y, "mask": mask}
 
 
+def ppo_vocabulary():
+    """event2word of the PPO pipeline.  Unlike the CP dictionary it does not depend on the dataset: it is the fixed
+    table ppo_policy/prepare_data.py:240-296 builds (value ranges per event type + <BOS>/<EOS>/<PAD>), so the
+    synthetic stand-in is the real vocabulary."""
+    values = {"Tempo": ["%d" % i for i in range(28, 211, 4)], "Bar": ["%d" % i for i in range(16)],
+              "Position": ["%d/16" % i for i in range(16)], "Pitch": ["%d" % i for i in range(22, 108)],
+              "Duration": ["%d" % i for i in range(64)], "Velocity": ["%d" % i for i in range(22)]}
+    e2w = {}
+    for k in PPO_KEYS:
+        names = ["%s %s" % (k, v) for v in values[k]] + ["%s <BOS>" % k, "%s <EOS>" % k, "%s <PAD>" % k]
+        e2w[k] = {name: i for i, name in enumerate(names)}
+    assert tuple(len(e2w[k]) for k in PPO_KEYS) == PPO_N
+    return e2w
+
+
 def load_ppo(path_dictionary, path_train_data, n_seq=8, T=1200, seed=1234):
     if os.path.exists(path_train_data) and os.path.exists(path_dictionary):
         with open(path_dictionary, "rb") as f:
@@ -67,10 +82,8 @@ def load_ppo(path_dictionary, path_train_data, n_seq=8, T=1200, seed=1234):
             ds = pickle.load(f)
         return dictionary, ds
     print("[data] %s not found: using synthetic CW tokens of the same schema" % path_train_data)
-    e2w = {k: {"%s_%d" % (k, i): i for i in range(n)} for k, n in zip(PPO_KEYS, PPO_N)}
+    e2w = ppo_vocabulary()
     w2e = {k: {i: e for e, i in v.items()} for k, v in e2w.items()}
     x, y, mask = _synth(n_seq, T, PPO_N, seed)
     return (e2w, w2e), {"train_x": x, "train_y": y, "mask": mask}
 
-
-_orig_load_dqn = load_dqn

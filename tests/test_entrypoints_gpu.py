@@ -161,7 +161,8 @@ def test_agent_pretrain_train_short_run(cuda, tmp_path, monkeypatch):
     from rlmg_amd.dqn_policy import agent_pretrain as A, config
     from rlmg_amd import data as cwdata
     old = _small(config.AgentConfig)
-    monkeypatch.setattr(cwdata, "load_dqn", lambda a, b, **kw: cwdata.__dict__["_orig_load_dqn"](a, b, n_seq=8, T=256))
+    real_load = cwdata.load_dqn
+    monkeypatch.setattr(cwdata, "load_dqn", lambda a, b, **kw: real_load(a, b, n_seq=8, T=256))
     try:
         loss = A.train(n_epoch=2, log=lambda *a: None)
         assert loss == loss and 0 < loss < 10

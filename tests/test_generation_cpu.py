@@ -99,3 +99,15 @@ def test_saver_log_format(tmp_path):
     assert key == "batch loss" and val == "1.2500000000" and step == "         1" and float(t) >= 0
     assert lines[2].startswith("epoch each loss | 1.0, 2.0 |          1 | ")
     assert lines[3] == "lr         | 3 |          7 | 0.5"
+
+
+def test_synthetic_vocabularies_have_the_reference_shapes():
+    from rlmg_amd import data
+    e2w = data.ppo_vocabulary()
+    assert [len(e2w[k]) for k in e2w] == [49, 19, 19, 89, 67, 25]          # prepare_data.py:247-291
+    assert e2w["Tempo"]["Tempo 28"] == 0 and e2w["Tempo"]["Tempo 208"] == 45 and e2w["Tempo"]["Tempo <PAD>"] == 48
+    assert e2w["Position"]["Position 15/16"] == 15 and e2w["Pitch"]["Pitch 107"] == 85
+    (d_e2w, d_w2e), ds = data.load_dqn("/nonexistent/a.npz", "/nonexistent/d.pkl", n_seq=2, T=16)
+    assert list(d_e2w) == list(data.DQN_KEYS) and [len(d_e2w[k]) for k in d_e2w] == list(data.DQN_N)
+    assert ds["x"].shape == (2, 16, 7) and ds["mask"].shape == (2, 16)
+    assert all(d_e2w[k][d_w2e[k][i]] == i for k in d_w2e for i in d_w2e[k])
