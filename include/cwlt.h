@@ -290,11 +290,15 @@ int cwlt_decode_gemv(const float* W, const float* bias, const float* xin, const 
  * tokens[row, a] (and in song[counter, row, a] when song != NULL and *counter < song_rows).  Replaces the six
  * `Categorical(softmax(y)).sample()` draws + torch.cat of ppo_policy/inference.py:115-141 (same distribution; the
  * generator is counter-based, keyed by (seed, *counter, row, a), so a captured graph draws fresh numbers per replay
- * as long as the caller advances *counter).  n_class / temperature: HOST arrays (temperature NULL = 1.0);
- * n_class[a] <= 256, n_attr <= 8; counter: device int64 (NULL = 0). */
-int cwlt_sample_categorical(const float* logits, const int* n_class, const float* temperature, int n_attr,
-                            int64_t rows, int64_t ld, uint64_t seed, const int64_t* counter, int64_t* tokens,
-                            int64_t* song, int64_t song_rows, void* stream);
+ * as long as the caller advances *counter).  top_p[a] < 1 restricts attribute a to its nucleus first -- the
+ * smallest set of most-probable classes whose mass exceeds top_p[a], renormalised: `nucleus` of
+ * dqn_policy/model.py:33-47, with temperature[a] its `softmax_with_temperature` (:19-21).
+ * n_class / temperature / top_p: HOST arrays (NULL = 1.0); n_class[a] <= 256, n_attr <= 8; counter: device int64
+ * (NULL = 0). */
+int cwlt_sample_categorical(const float* logits, const int* n_class, const float* temperature,
+                            const float* top_p, int n_attr, int64_t rows, int64_t ld, uint64_t seed,
+                            const int64_t* counter, int64_t* tokens, int64_t* song, int64_t song_rows,
+                            void* stream);
 
 #ifdef __cplusplus
 }

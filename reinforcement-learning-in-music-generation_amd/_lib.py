@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -67,7 +67,7 @@ _SIGNATURES = {
     "cwlt_decode_workspace_floats": [ctypes.POINTER(DecodeModel)],
     "cwlt_decode_step": [ctypes.POINTER(DecodeModel), _ptr, _ptr, _ptr, _ptr, _c_int, _ptr],
     "cwlt_decode_gemv": [_ptr] * 7 + [_c_f32] + [_ptr] * 3 + [_c_int] * 4 + [_c_i64] * 4 + [_ptr],
-    "cwlt_sample_categorical": [_ptr, _ptr, _ptr, _c_int, _c_i64, _c_i64, _c_u64, _ptr, _ptr, _ptr, _c_i64, _ptr],
+    "cwlt_sample_categorical": [_ptr, _ptr, _ptr, _ptr, _c_int, _c_i64, _c_i64, _c_u64, _ptr, _ptr, _ptr, _c_i64, _ptr],
     "cwlt_heads_blocks": [_c_i64],
     "cwlt_heads_fwd": [_ptr, _ptr, _c_int] + [_ptr] * 7 + [_c_i64, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_heads_ce_bwd": [_ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],

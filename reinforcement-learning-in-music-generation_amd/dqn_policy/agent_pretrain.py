@@ -115,7 +115,7 @@ num_songs = 5
 bar_production = 50                               # testing-no-type-cp.py:35
 
 
-def generate(n_songs=None, bar_cond=None, max_tokens=None, log=print):
+def generate(n_songs=None, bar_cond=None, max_tokens=None, log=print, device_sampling=False):
     """agent_pretrain.py:636-706 / testing-no-type-cp.py:182-260: build the recurrent-form net, load
     ./ckpt/_params.pt when present, sample `num_songs` songs, write get_<i>.mid + runtime_stats.json."""
     from rlmg_amd import generation, midi
@@ -134,7 +134,8 @@ def generate(n_songs=None, bar_cond=None, max_tokens=None, log=print):
         log("[*] %s not found: sampling from freshly initialised weights" % path_saved_ckpt)
     return generation.generate(net, word2event, n_songs=num_songs if n_songs is None else n_songs,
                                bar_cond=bar_production if bar_cond is None else bar_cond, path_gendir=path_gendir,
-                               write_midi=midi.write_midi, max_tokens=max_tokens, log=log)
+                               write_midi=midi.write_midi, max_tokens=max_tokens, log=log,
+                               device_sampling=device_sampling)
 
 
 if __name__ == "__main__":

@@ -792,10 +792,11 @@ def decode_gemv(w, bias, x, ln=None, ln2=None, eps=1e-5, res=None, act=None, wan
     return (out, xn) if want_normed else out
 
 
-def sample_categorical(logits, n_class, tokens, seed, counter=None, song=None, temperature=None):
+def sample_categorical(logits, n_class, tokens, seed, counter=None, song=None, temperature=None, top_p=None):
     """tokens[row, a] ~ Categorical(softmax(logits[row, segment a] / temperature[a])) on the device
     (csrc/sample.hip; ppo_policy/inference.py:115-141).  logits (rows, >= sum n_class) f32; tokens (rows, A) int64
-    written in place; counter: device int64 scalar tensor that keys the draw (and indexes `song` (T, rows, A))."""
+    written in place; counter: device int64 scalar tensor that keys the draw (and indexes `song` (T, rows, A));
+    top_p[a] < 1 (or None = off) samples attribute a from its nucleus (dqn_policy/model.py:33-47)."""
     if logits.dtype != torch.float32 or tokens.dtype != torch.int64:
         raise TypeError("sample_categorical takes f32 logits and int64 tokens")
     rows, A = logits.shape[0], len(n_class)
@@ -804,7 +805,8 @@ def sample_categorical(logits, n_class, tokens, seed, counter=None, song=None, t
     if logits.stride(-1) != 1:
         logits = logits.contiguous()
     temp = None if temperature is None else (ctypes.c_float * A)(*[float(t) for t in temperature])
-    _call("cwlt_sample_categorical", _lib.dev(logits, "logits"), _lib.int_array(n_class), temp, A, rows,
+    topp = None if top_p is None else (ctypes.c_float * A)(*[1.0 if p is None else float(p) for p in top_p])
+    _call("cwlt_sample_categorical", _lib.dev(logits, "logits"), _lib.int_array(n_class), temp, topp, A, rows,
           logits.stride(0), int(seed) & 0xFFFFFFFFFFFFFFFF, _lib.opt(counter), _lib.dev(tokens, "tokens"), _lib.opt(song),
           0 if song is None else song.shape[0], _lib.stream_ptr())
     return tokens

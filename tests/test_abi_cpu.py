@@ -49,7 +49,7 @@ def test_argument_validation_without_gpu(built):
     assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 0, null) == 1001
     assert lib.cwlt_add_dropout_layernorm_fwd(null, null, null, null, null, null, null, null, 4, 512, 1e-5, 0.0, 0, null, 0, null) == 1001
     assert lib.cwlt_ln_blocks(65536) == 1024 and lib.cwlt_ln_blocks(1) == 1
-    assert lib.cwlt_sample_categorical(buf, (ctypes.c_int * 2)(5, 300), None, 2, 1, 305, 0, null, buf, null, 0, null) == 1001
+    assert lib.cwlt_sample_categorical(buf, (ctypes.c_int * 2)(5, 300), None, None, 2, 1, 305, 0, null, buf, null, 0, null) == 1001
     # generation step: an incomplete model description is refused before any launch
     m = built.DecodeModel()
     assert lib.cwlt_decode_workspace_floats(ctypes.byref(m)) == -1

@@ -100,6 +100,21 @@ def test_inference_from_scratch_and_generate(cuda, tmp_path):
     # max_tokens caps an otherwise unbounded song
     res = generation.inference_from_scratch(net, w2e, bar_cond=10 ** 6, max_tokens=20)
     assert len(res) == 20
+    # device-side sampling: same loop semantics (starts with the Bar token, stops WITH the token that opens bar 4),
+    # reproducible under torch.manual_seed, graph replay == eager launches
+    songs = []
+    for graph in (True, False, True):
+        torch.manual_seed(11)
+        sess = generation.DecodeSession(net, graph=graph)
+        songs.append(generation.inference_from_scratch(net, w2e, bar_cond=4, session=sess, device_sampling=True,
+                                                       chunk=16))
+    assert songs[0].tolist() == songs[1].tolist() == songs[2].tolist()
+    song = songs[0]
+    assert song[0].tolist() == generation.INIT_CW[0].tolist()
+    bars = [w2e["bar-beat"][int(r[2])] == "Bar" for r in song]
+    assert sum(bars) == 4 and bars[-1] and all((song[:, i] < n).all() for i, n in enumerate(N_CLASS))
+    res = generation.inference_from_scratch(net, w2e, bar_cond=10 ** 6, max_tokens=40, device_sampling=True, chunk=16)
+    assert len(res) == 40
 
 
 def test_fused_decode_batch_of_songs_and_weight_reload(cuda):
@@ -193,6 +208,29 @@ def test_device_categorical_sampler_distribution_and_determinism(cuda):
         ids = toks[:, a].cpu().numpy()
         assert ids.min() >= 0 and ids.max() < n
         freq = np.bincount(ids, minlength=n) / T
+        sigma = np.sqrt(p * (1 - p) / T)
+        assert (np.abs(freq - p) < 5 * sigma + 1e-4).all(), a
+        o += n
+    # nucleus: classes outside the reference's nucleus (dqn_policy/model.py:33-47) are never drawn, the rest follow
+    # the renormalised probabilities
+    top_p = [0.9, 0.99, None, 0.5, 0.9, None]
+    ops.sample_categorical(rows, n_class, toks, seed=99, temperature=temp, top_p=top_p)
+    o = 0
+    for a, n in enumerate(n_class):
+        z = logits[0, o:o + n].cpu().numpy() / temp[a]
+        p = np.exp(z) / np.sum(np.exp(z))
+        if top_p[a] is not None:
+            q = p / (sum(p) + 1e-5)
+            order = np.argsort(q)[::-1]
+            after = np.cumsum(np.sort(q)[::-1]) > top_p[a]
+            keep = order[:np.where(after)[0][0] + 1] if after.sum() > 0 else order
+            mask = np.zeros(n, dtype=bool)
+            mask[keep] = True
+            p = np.where(mask, p, 0.0)
+            p = p / p.sum()
+        ids = toks[:, a].cpu().numpy()
+        freq = np.bincount(ids, minlength=n) / T
+        assert (freq[p == 0] == 0).all(), a
         sigma = np.sqrt(p * (1 - p) / T)
         assert (np.abs(freq - p) < 5 * sigma + 1e-4).all(), a
         o += n

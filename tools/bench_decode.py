@@ -60,6 +60,17 @@ def main():
         print(json.dumps({"metric": "decode CW-tokens/s (1 song, sampling on the device)", "graph": True, "fused": True,
                           "tokens": n_tok, "with_sampling": round(n_tok / (t1 - t0), 1),
                           "us_per_token": round((t1 - t0) / n_tok * 1e6, 1)}), flush=True)
+        # the DQN-side loop (inference_from_scratch) with its temperature / nucleus samplers on the device
+        w2e = {"bar-beat": {i: "x" for i in range(n_class[2])}}
+        w2e = {k: w2e.get(k, {}) for k in ("tempo", "chord", "bar-beat", "pitch", "duration", "velocity")}
+        sess = generation.DecodeSession(net, graph=True)
+        generation.inference_from_scratch(net, w2e, 10 ** 9, max_tokens=64, session=sess, device_sampling=True)
+        t0 = time.perf_counter()
+        res = generation.inference_from_scratch(net, w2e, 10 ** 9, max_tokens=n_tok, session=sess, device_sampling=True)
+        t1 = time.perf_counter()
+        print(json.dumps({"metric": "decode CW-tokens/s (1 song, inference_from_scratch, nucleus sampling on the device)",
+                          "tokens": len(res), "with_sampling": round(len(res) / (t1 - t0), 1),
+                          "us_per_token": round((t1 - t0) / len(res) * 1e6, 1)}), flush=True)
         for n in a.songs:
             sess = generation.DecodeSession(net, graph=True, fused=True, n_songs=n)
             tok = np.tile(generation.INIT_CW[0], (n, 1))
