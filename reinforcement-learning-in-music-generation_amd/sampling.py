@@ -1,33 +1,54 @@
 """Host-side (numpy) token samplers used at generation time -- dqn_policy/model.py:19-55,
-ppo_policy/model.py:28-64.  They consume `np.random` exactly as the reference does (same number and order of
-draws, same float32 arithmetic incl. Python's sequential `sum`), so a seeded run reproduces its token stream.
+ppo_policy/model.py:28-64.  They consume `np.random` exactly as the reference does (one uniform double per draw,
+in the reference's order of draws) and do its float32 arithmetic step for step, so a seeded run reproduces its
+token stream bit for bit (tests/golden/dqn_generation_small.npz; tests/test_generation_cpu.py also checks them
+against a line-by-line restatement on random logits).
+
+They are on the critical path of host-sampled generation (one call per attribute per token), so the Python-level
+loops of the reference are replaced by numpy calls with the SAME rounding:
+  * `sum(x)` over a float32 array (sequential float32 adds)  ==  `np.cumsum(x)[-1]` (cumsum is sequential too);
+  * `np.random.choice(a, size=1, p=p)`  ==  `a[searchsorted(cumsum(float64(p)) / total, random_sample(), 'right')]`,
+    which is what RandomState.choice does after validating p; non-finite p goes to np.random.choice itself so
+    that it raises what the reference raises.
 """
 import numpy as np
 
 
+def _seq_sum(x):
+    """Python's sum() over a float32 vector: left-to-right float32 additions."""
+    return x.cumsum()[-1]
+
+
+def _choice(values, p):
+    """np.random.choice(values, size=1, p=p)[0] without its argument validation (same draw, same result)."""
+    cdf = p.astype(np.float64).cumsum()
+    total = cdf[-1]
+    if not abs(total - 1.0) <= 1e-4:                              # NaN / inf / not normalised (p >= 0: it is exp / sum)
+        return np.random.choice(values, size=1, p=p)[0]          # let numpy raise / decide, as in the reference
+    cdf /= total
+    return values[cdf.searchsorted(np.random.random_sample(), side="right")]
+
+
 def softmax_with_temperature(logits, temperature):
-    return np.exp(logits / temperature) / np.sum(np.exp(logits / temperature))
+    e = np.exp(logits / temperature)
+    return e / np.sum(e)
 
 
 def weighted_sampling(probs):
-    probs = probs / sum(probs)
-    order = np.argsort(probs)[::-1]
-    return np.random.choice(order, size=1, p=np.sort(probs)[::-1])[0]
+    probs = probs / _seq_sum(probs)
+    order = probs.argsort()[::-1]
+    return _choice(order, probs[order])
 
 
 def nucleus(probs, p):
-    probs = probs / (sum(probs) + 1e-5)
-    order = np.argsort(probs)[::-1]
-    cusum = np.cumsum(np.sort(probs)[::-1])
-    after = cusum > p
-    if sum(after) > 0:
-        last = np.where(after)[0][0] + 1
-        cand = order[:last]
-    else:
-        cand = order[:]
-    cp = [probs[i] for i in cand]
-    cp = cp / sum(cp)
-    return np.random.choice(cand, size=1, p=cp)[0]
+    probs = probs / (_seq_sum(probs) + 1e-5)
+    order = probs.argsort()[::-1]
+    sorted_probs = probs[order]
+    hit = (sorted_probs.cumsum() > p).nonzero()[0]
+    cand = order[:hit[0] + 1] if hit.size else order
+    cp = sorted_probs[:cand.size]
+    cp = cp / _seq_sum(cp)
+    return _choice(cand, cp)
 
 
 def sampling(logit, p=None, t=1.0):

@@ -111,3 +111,49 @@ def test_synthetic_vocabularies_have_the_reference_shapes():
     assert list(d_e2w) == list(data.DQN_KEYS) and [len(d_e2w[k]) for k in d_e2w] == list(data.DQN_N)
     assert ds["x"].shape == (2, 16, 7) and ds["mask"].shape == (2, 16)
     assert all(d_e2w[k][d_w2e[k][i]] == i for k in d_w2e for i in d_w2e[k])
+
+
+def _plain_softmax(logits, temperature):
+    return np.exp(logits / temperature) / np.sum(np.exp(logits / temperature))
+
+
+def _plain_weighted(probs):
+    probs = probs / sum(probs)
+    sorted_probs = np.sort(probs)[::-1]
+    sorted_index = np.argsort(probs)[::-1]
+    return np.random.choice(sorted_index, size=1, p=sorted_probs)[0]
+
+
+def _plain_nucleus(probs, p):
+    probs = probs / (sum(probs) + 1e-5)
+    sorted_probs = np.sort(probs)[::-1]
+    sorted_index = np.argsort(probs)[::-1]
+    after = np.cumsum(sorted_probs) > p
+    if sum(after) > 0:
+        cand = sorted_index[:np.where(after)[0][0] + 1]
+    else:
+        cand = sorted_index[:]
+    cp = [probs[i] for i in cand]
+    cp = cp / sum(cp)
+    return np.random.choice(cand, size=1, p=cp)[0]
+
+
+def test_fast_samplers_equal_a_line_by_line_restatement():
+    """sampling.py replaces the Python-level loops of dqn_policy/model.py:19-55 by numpy calls with the same rounding:
+    on random logits the drawn ids AND the generator state afterwards equal those of the plain statement."""
+    from rlmg_amd import sampling as S
+    rng = np.random.default_rng(0)
+    for trial in range(1500):
+        n = int(rng.choice([18, 25, 56, 87, 135]))
+        logit = (rng.standard_normal(n) * rng.choice([0.3, 2.0, 8.0])).astype(np.float32)
+        t = float(rng.choice([1.0, 1.2, 2.0, 5.0]))
+        p = rng.choice([None, 0.9, 0.99, 0.5])
+        np.random.seed(trial)
+        probs = _plain_softmax(logit, t)
+        want = _plain_nucleus(probs, p) if p is not None else _plain_weighted(probs)
+        state_want = np.random.get_state()[1].copy(), np.random.get_state()[2]
+        np.random.seed(trial)
+        got = S.sampling(logit, p=p, t=t)
+        state_got = np.random.get_state()[1], np.random.get_state()[2]
+        assert got == want, (trial, n, t, p)
+        assert state_got[1] == state_want[1] and (state_got[0] == state_want[0]).all()
