@@ -299,7 +299,7 @@ def inference_from_scratch(model, word2event, bar_cond, max_tokens=None, log=Non
     device_sampling=False: the reference's numpy samplers on the host (a seeded np.random reproduces its stream).
     device_sampling=True: the same per-attribute temperature / nucleus settings drawn on the device
     (`cwlt_sample_categorical`); the host only looks at the song every `chunk` tokens to count bars, and cuts it
-    where the reference's loop would have stopped.  Same distribution, different random stream, ~1.7x faster."""
+    where the reference's loop would have stopped.  Same distribution, different random stream, ~1.2x faster (no host round trip per token)."""
     classes = list(word2event.keys())
     sess = session or DecodeSession(model)
     sess.reset()
