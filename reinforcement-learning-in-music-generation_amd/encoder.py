@@ -34,39 +34,48 @@ class _EncoderLayerFn(torch.autograd.Function):
     CausalLinearAttention), x: (N, L, D) -> (N, L, D)."""
 
     @staticmethod
-    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, H, p, seeds, layer):
+    def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, H, p, seeds, layer,
+                shadow=None):
         N, L, D = x.shape
         R = N * L
         adt = x.dtype
         x2 = x.reshape(R, D)
-        wqkv = torch.cat([wq, wk, wv], 0).to(adt)
-        bqkv = torch.cat([bq, bk, bv], 0).to(adt)
-        wo_a, w1_a, w2_a = wo.to(adt), w1.to(adt), w2.to(adt)
+        if shadow is not None:
+            # compute-dtype copies kept (and refreshed with one multi-tensor copy) by the encoder: ops.ShadowSet
+            wqkv, bqkv, wo_a, bo_a, w1_a, w2_a, b2_a = shadow
+        else:
+            wqkv = torch.cat([wq, wk, wv], 0).to(adt)
+            bqkv = torch.cat([bq, bk, bv], 0).to(adt)
+            wo_a, w1_a, w2_a = wo.to(adt), w1.to(adt), w2.to(adt)
+            bo_a, b2_a = bo.to(adt), b2.to(adt)
         g1f, be1f, g2f, be2f, b1f = (ops._f32(t) for t in (g1, be1, g2, be2, b1))
 
         qkv = torch.addmm(bqkv, x2, wqkv.t())                              # (R, 3D)  MFMA
         qkv5 = qkv.view(N, L, 3, H, D // H)
         _, _, _, a, zinv = ops.cla_fwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2])
         a2 = a.view(R, D)
-        o = torch.addmm(bo.to(adt), a2, wo_a.t())                          # MFMA
+        o = torch.addmm(bo_a, a2, wo_a.t())                                # MFMA
         s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
         del o
         h = torch.mm(x1, w1_a.t())                                         # (R, F)  MFMA, bias in next kernel
         g = ops.gelu_fwd(h, b1f, p, seeds[1])
-        y = torch.addmm(b2.to(adt), g, w2_a.t())                           # MFMA
+        y = torch.addmm(b2_a, g, w2_a.t())                                 # MFMA
         s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
         del y
 
-        ctx.save_for_backward(x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2,
-                              wqkv, wo_a, w1_a, w2_a, g1f, g2f, b1f)
+        ctx.save_for_backward(x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2, g1f, g2f, b1f)
+        # The weight copies may be the encoder's persistent shadow buffers, which a LATER forward refreshes in place
+        # (same values unless an optimizer step came in between -- PPO runs two actor forwards before one backward),
+        # so they are kept as plain attributes rather than version-checked saved tensors.
+        ctx.weights = (wqkv, wo_a, w1_a, w2_a)
         ctx.cfg = (N, L, D, H, p, seeds)
         ctx.layer = layer
         return out.view(N, L, D)
 
     @staticmethod
     def backward(ctx, dout):
-        (x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2,
-         wqkv, wo_a, w1_a, w2_a, g1f, g2f, b1f) = ctx.saved_tensors
+        x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2, g1f, g2f, b1f = ctx.saved_tensors
+        wqkv, wo_a, w1_a, w2_a = ctx.weights
         N, L, D, H, p, seeds = ctx.cfg
         R = N * L
         dout2 = dout.reshape(R, D)
@@ -80,7 +89,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         ds2, dy, dg2, dbe2, db2 = ops.ln_bwd(dout2, None, s2, g2f, mean2, rstd2, p, seeds[2])
         # Input-gradient GEMMs run as NT products on explicitly transposed weights (2 MB each): hipBLASLt's TN kernels
         # for these shapes are 20-30 % faster than its NN kernels (tuning table: 0.94 vs 1.20 ms for FFN2 at B = 512)
-        nt = os.environ.get("CWLT_DGRAD_NT", "1") != "0" and dy.dtype == torch.bfloat16
+        # ... at large R; below ~16k rows the three 2 MB transposes cost more than the GEMMs gain
+        nt = os.environ.get("CWLT_DGRAD_NT", "1") != "0" and dy.dtype == torch.bfloat16 and R >= 16384
 
         def dgrad(g_, w_):
             return torch.mm(g_, w_.t().contiguous().t()) if nt else torch.mm(g_, w_)
@@ -117,12 +127,12 @@ class _EncoderLayerFn(torch.autograd.Function):
                                (layer.linear2.weight, dw2), (layer.linear2.bias, db2),
                                (layer.norm1.weight, dg1), (layer.norm1.bias, dbe1),
                                (layer.norm2.weight, dg2), (layer.norm2.bias, dbe2)))
-            return (dx.view(N, L, D),) + (None,) * 20
+            return (dx.view(N, L, D),) + (None,) * 21
         dwqkv = dwqkv.float()
         return (dx.view(N, L, D),
                 dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
                 dwo.float(), dbo, dw1.float(), db1, dw2.float(), db2, dg1, dbe1, dg2, dbe2,
-                None, None, None, None)
+                None, None, None, None, None)
 
 
 class AttentionLayer(nn.Module):
@@ -147,7 +157,15 @@ class TransformerEncoderLayer(nn.Module):
         self.norm2 = nn.LayerNorm(d_model)
         self.dropout = nn.Dropout(dropout)  # only carries p / train-eval state
 
-    def forward(self, x, attn_mask=None):
+    def shadow_groups(self):
+        """Parameter groups of one layer for ops.ShadowSet, in the order _EncoderLayerFn unpacks them."""
+        at = self.attention
+        return [(at.query_projection.weight, at.key_projection.weight, at.value_projection.weight),
+                (at.query_projection.bias, at.key_projection.bias, at.value_projection.bias),
+                (at.out_projection.weight,), (at.out_projection.bias,), (self.linear1.weight,), (self.linear2.weight,),
+                (self.linear2.bias,)]
+
+    def forward(self, x, attn_mask=None, shadow=None):
         if attn_mask is not None and not getattr(attn_mask, "lower_triangular", False):
             raise RuntimeError("CausalLinearAttention only supports full lower triangular masks")
         p = self.dropout.p if self.training else 0.0
@@ -157,7 +175,7 @@ class TransformerEncoderLayer(nn.Module):
             x, at.query_projection.weight, at.query_projection.bias, at.key_projection.weight, at.key_projection.bias,
             at.value_projection.weight, at.value_projection.bias, at.out_projection.weight, at.out_projection.bias,
             self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-            self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, at.n_heads, p, seeds, self)
+            self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, at.n_heads, p, seeds, self, shadow)
 
 
 class TransformerEncoder(nn.Module):
@@ -165,14 +183,20 @@ class TransformerEncoder(nn.Module):
         super().__init__()
         self.layers = nn.ModuleList(layers)
         self.norm = norm_layer
+        self._shadow = None                                  # ops.ShadowSet of the layers' compute-dtype weights
 
     def forward(self, x, attn_mask=None, length_mask=None):
         if length_mask is not None:
             raise NotImplementedError("the reference never passes a length mask (dqn_policy/model.py:232)")
         if not x.is_cuda:
             raise RuntimeError("rlmg_amd encoder runs on the GPU only (no CPU fallback)")
-        for layer in self.layers:
-            x = layer(x, attn_mask)
+        per = 7                                             # buffers per layer (TransformerEncoderLayer.shadow_groups)
+        sh = self._shadow
+        if sh is None or not sh.matches(x.dtype, x.device):
+            sh = self._shadow = ops.ShadowSet([g for layer in self.layers for g in layer.shadow_groups()], x.dtype)
+        bufs = sh.refresh()
+        for i, layer in enumerate(self.layers):
+            x = layer(x, attn_mask, tuple(bufs[per * i:per * (i + 1)]))
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x

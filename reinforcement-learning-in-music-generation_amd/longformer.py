@@ -93,6 +93,7 @@ class LongformerModel(nn.Module):
         self.embeddings = _Embeddings(vocab_size, hidden_size, max_position_embeddings, type_vocab_size,
                                       layer_norm_eps, pad_token_id)
         self.encoder = _Encoder(num_hidden_layers, hidden_size, intermediate_size, layer_norm_eps)
+        self._shadow = None                                  # ops.ShadowSet used by the no-grad scoring path
         self.pooler = _Dense(hidden_size, hidden_size)
         self.n_heads = num_attention_heads
         self.one_sided_window = attention_window // 2
@@ -166,21 +167,30 @@ class LongformerModel(nn.Module):
             h = ops.posenc_dropout(h, None, L, ph, ops.next_seed())
         mask = None if attention_mask is None else attention_mask.reshape(B, L).float()
         H = self.n_heads
-        for layer in self.encoder.layer:
-            sa = layer.attention.self
-            wqkv = torch.cat([sa.query.weight, sa.key.weight, sa.value.weight], 0).to(adt)
-            bqkv = torch.cat([sa.query.bias, sa.key.bias, sa.value.bias], 0).to(adt)
+        # compute-dtype copies of the weights: persistent, refreshed by one multi-tensor copy (ops.ShadowSet) instead
+        # of nine cast / cat kernels per layer per call -- scoring runs 40 times per DQN env step
+        sh = self._shadow
+        if sh is None or not sh.matches(adt, x.device):
+            groups = []
+            for layer in self.encoder.layer:
+                sa, ao, it, lo = layer.attention.self, layer.attention.output, layer.intermediate.dense, layer.output
+                groups += [(sa.query.weight, sa.key.weight, sa.value.weight), (sa.query.bias, sa.key.bias, sa.value.bias),
+                           (ao.dense.weight,), (ao.dense.bias,), (it.weight,), (lo.dense.weight,), (lo.dense.bias,)]
+            sh = self._shadow = ops.ShadowSet(groups, adt)
+        bufs = sh.refresh()
+        for li, layer in enumerate(self.encoder.layer):
+            wqkv, bqkv, wo, bo, w1, w2, b2 = bufs[7 * li:7 * li + 7]
             qkv = torch.addmm(bqkv, h, wqkv.t()).view(B, L, 3, H, Dm // H)
             a = ops.band_attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], mask, self.one_sided_window, pa,
                                    ops.next_seed() if pa > 0 else 0).view(B * L, Dm)
             ao = layer.attention.output
-            o = torch.addmm(ao.dense.bias.to(adt), a, ao.dense.weight.to(adt).t())
+            o = torch.addmm(bo, a, wo.t())
             _, h1, _, _ = ops.ln_fwd(h, o, ops._f32(ao.LayerNorm.weight), ops._f32(ao.LayerNorm.bias), self.eps, ph,
                                      ops.next_seed() if ph > 0 else 0, save_s=False)
             it = layer.intermediate.dense
-            g = ops.gelu_fwd(torch.mm(h1, it.weight.to(adt).t()), ops._f32(it.bias), 0.0, 0)
+            g = ops.gelu_fwd(torch.mm(h1, w1.t()), ops._f32(it.bias), 0.0, 0)
             lo = layer.output
-            y = torch.addmm(lo.dense.bias.to(adt), g, lo.dense.weight.to(adt).t())
+            y = torch.addmm(b2, g, w2.t())
             _, h, _, _ = ops.ln_fwd(h1, y, ops._f32(lo.LayerNorm.weight), ops._f32(lo.LayerNorm.bias), self.eps, ph,
                                     ops.next_seed() if ph > 0 else 0, save_s=False)
         return LongformerOutput(h.view(B, L, Dm))

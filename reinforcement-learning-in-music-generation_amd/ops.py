@@ -261,7 +261,60 @@ class GraphedCall:
         for s, a in zip(static, args):
             s.copy_(a)
         graph.replay()
+        if self.grad:
+            weights_changed()       # the captured optimizer step moved the parameters without bumping their versions
         return out
+
+
+
+# --------------------------------------------------------------------------------------------------
+# compute-dtype copies of the master parameters
+# --------------------------------------------------------------------------------------------------
+# The f32 master weights are used in bf16 (and Q/K/V row-stacked) by every layer.  Casting them per call is seven
+# 1-4 MB copy kernels + two cat kernels per layer per forward: nothing at B*T = 524 288 rows, but a third of the GPU
+# time of the launch-bound RL steps (window 50: 108 such kernels per 12-layer trunk forward).  A ShadowSet keeps
+# persistent copies and refreshes ALL of them with one multi-tensor copy, and only when a parameter changed.
+_WEIGHTS_EPOCH = [0]      # bumped when parameters change behind autograd's back (replay of a captured optimizer step)
+
+
+def weights_changed():
+    _WEIGHTS_EPOCH[0] += 1
+
+
+class ShadowSet:
+    """`groups`: tuples of parameters; group i becomes ONE buffer of `dtype` with its members stacked along dim 0
+    (a single-member group is a plain cast).  `refresh()` -> list of buffers, up to date with the parameters.
+
+    Freshness is tracked by the parameters' autograd version counters (optimizer steps, copy_, load_state_dict bump
+    them) plus `weights_changed()` for graph replays.  While a hipGraph is being CAPTURED the copy is always
+    recorded, so that every replay re-derives the buffers from the then-current parameters."""
+
+    def __init__(self, groups, dtype):
+        self.dtype = dtype
+        self.device = groups[0][0].device
+        self.bufs, self.dst, self.src = [], [], []
+        for g in groups:
+            rows = sum(p.shape[0] for p in g)
+            buf = torch.empty((rows,) + tuple(g[0].shape[1:]), dtype=dtype, device=self.device)
+            o = 0
+            for p in g:
+                self.dst.append(buf[o:o + p.shape[0]])
+                self.src.append(p)
+                o += p.shape[0]
+            self.bufs.append(buf)
+        self.tag = None
+
+    def matches(self, dtype, device):
+        return self.dtype == dtype and self.device == device and all(p.device == device for p in self.src)
+
+    def refresh(self):
+        capturing = torch.cuda.is_current_stream_capturing()
+        tag = (_WEIGHTS_EPOCH[0],) + tuple(p._version for p in self.src)
+        if capturing or tag != self.tag:
+            with torch.no_grad():
+                torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
+            self.tag = None if capturing else tag
+        return self.bufs
 
 
 # --------------------------------------------------------------------------------------------------
@@ -477,23 +530,40 @@ class LinearWgradFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        w16 = w.to(x.dtype)
-        ctx.save_for_backward(x, w16)
-        return torch.addmm(b.to(x.dtype), x, w16.t())
+        w16, b16 = _cast_pair(w, b, x.dtype)
+        ctx.save_for_backward(x)
+        ctx.w16 = w16              # a persistent shadow buffer when w is a Parameter: not version-tracked on purpose
+        return torch.addmm(b16, x, w16.t())
 
     @staticmethod
     def backward(ctx, dy):
-        x, w16 = ctx.saved_tensors
+        (x,), w16 = ctx.saved_tensors, ctx.w16
         dy = dy.contiguous()
         dx = torch.mm(dy, w16) if ctx.needs_input_grad[0] else None
         dw = wgrad(dy, x) if wgrad_supported(dy, x) else torch.mm(dy.t(), x).float()
         return dx, dw, colsum(dy)
 
 
+def _cast_pair(w, b, dtype):
+    """(w, b) in `dtype`; for a Parameter pair through a ShadowSet kept on the weight (no per-call cast kernels)."""
+    if w.dtype == dtype and b.dtype == dtype:
+        return w, b
+    if isinstance(w, torch.nn.Parameter) and isinstance(b, torch.nn.Parameter):
+        sh = getattr(w, "_cwlt_shadow", None)
+        if sh is None or not sh.matches(dtype, w.device) or sh.src[1] is not b:
+            sh = w._cwlt_shadow = ShadowSet([(w,), (b,)], dtype)
+        w16, b16 = sh.refresh()
+        return w16, b16
+    return w.to(dtype), b.to(dtype)
+
+
 def linear(x, w, b):
     """F.linear(x, w.to(x.dtype), b.to(x.dtype)) with the f32-gradient backward above when x is bf16."""
     if x.dtype == torch.bfloat16 and x.dim() == 2 and x.is_contiguous() and torch.is_grad_enabled():
         return LinearWgradFn.apply(x, w, b)
+    if not torch.is_grad_enabled():
+        w16, b16 = _cast_pair(w, b, x.dtype)
+        return torch.nn.functional.linear(x, w16, b16)
     return torch.nn.functional.linear(x, w.to(x.dtype), b.to(x.dtype))
 
 

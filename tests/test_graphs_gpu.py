@@ -199,3 +199,80 @@ def test_graphed_ppo_update_policy_matches_eager(cuda, tmp_path, monkeypatch):
     finally:
         config.ActorConfig.update(old_a)
         config.DiscriConfig.update(old_d)
+
+
+def test_weight_shadows_follow_the_parameters(cuda, tmp_path, monkeypatch):
+    """ops.ShadowSet (persistent bf16 copies of the master weights): an eager forward always computes with the current
+    parameters -- after an in-place update, after load_state_dict, after the replay of a captured optimizer step --
+    and two forwards before one backward (PPO's pattern) give the gradients of recomputed casts."""
+    monkeypatch.chdir(tmp_path)
+    from rlmg_amd.dqn_policy import IRL_dqn_train as T, config, model
+    old = _small(config.AgentConfig)
+    try:
+        n_class = [56, 135, 18, 87, 18, 25]
+        g = torch.Generator().manual_seed(4)
+        x = torch.stack([torch.randint(0, n, (2, 32), generator=g) for n in n_class], -1).to(cuda)
+
+        def fresh_forward(net):                     # the same net with every shadow dropped: casts recomputed
+            enc = net.transformer_encoder
+            keep = enc._shadow
+            enc._shadow = None
+            for p in net.parameters():
+                p.__dict__.pop("_cwlt_shadow", None)
+            with torch.no_grad():
+                out = net.forward_hidden(x).float().clone()
+            enc._shadow = keep
+            return out
+
+        net = fill_params(model.LinearTransformer(n_class), seed=5).to(cuda).eval()
+        net.compute_dtype = torch.bfloat16
+        with torch.no_grad():
+            h0 = net.forward_hidden(x).float().clone()
+            lin = net.transformer_encoder.layers[1].linear2
+            lin.weight.mul_(1.5)                                            # in-place update: version bump
+            h1 = net.forward_hidden(x).float().clone()
+        assert (h1 - h0).abs().max().item() > 1e-3 and torch.equal(h1, fresh_forward(net))
+        sd = {k: v.clone() for k, v in net.state_dict().items()}
+        sd["transformer_encoder.layers.0.attention.key_projection.weight"] *= 0.5
+        net.load_state_dict(sd)
+        with torch.no_grad():
+            h2 = net.forward_hidden(x).float().clone()
+        assert (h2 - h1).abs().max().item() > 1e-4 and torch.equal(h2, fresh_forward(net))
+
+        # captured optimizer step: parameters move without a version bump; GraphedCall reports it
+        monkeypatch.setattr(ops, "GRAPHS_ENABLED", True)
+        monkeypatch.setattr(ops, "TRAIN_GRAPHS", True)
+        agent = T.DQN(n_class, Pretrain=False)
+        fill_params(agent.eval_net, seed=61)
+        agent.eval_net.eval()
+        agent.target_net.eval()
+        B = 6
+        tok = lambda *s: torch.stack([torch.randint(0, n, s, generator=g) for n in n_class], -1).to(cuda)  # noqa: E731
+        m = torch.ones(B, 50, device=cuda)
+        for i in range(5):
+            tr = {"state": tok(B, 50), "action": tok(B, 25), "reward": torch.rand(B, 1, generator=g),
+                  "nextstate": tok(B, 50), "done": torch.zeros(B, 1)}
+            agent.update(tr, dict(tr), m, False, 0)
+            with torch.no_grad():
+                got = agent.eval_net.forward_hidden(x).float().clone()
+            assert torch.equal(got, fresh_forward(agent.eval_net)), i
+        assert len(agent._graph_update.graphs) == 1
+
+        # two forwards, then the backward of the FIRST one: no autograd version error, gradients as with fresh casts
+        net.train()
+        tgt = torch.stack([torch.randint(0, n, (2, 32), generator=g) for n in n_class], -1).to(cuda)
+        mask = torch.ones(2, 32, device=cuda)
+        torch.manual_seed(3)
+        l_first = sum(net.train_step(x, tgt, mask))
+        sum(net.train_step(x, tgt, mask))
+        net.zero_grad()
+        l_first.backward()
+        g_shadow = net.transformer_encoder.layers[0].linear1.weight.grad.clone()
+        net.transformer_encoder._shadow = None
+        torch.manual_seed(3)
+        l_ref = sum(net.train_step(x, tgt, mask))
+        net.zero_grad()
+        l_ref.backward()
+        assert torch.equal(g_shadow, net.transformer_encoder.layers[0].linear1.weight.grad)
+    finally:
+        config.AgentConfig.update(old)
