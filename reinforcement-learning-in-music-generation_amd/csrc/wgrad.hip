@@ -189,6 +189,7 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
     if (N1 <= 0 || N2 <= 0 || (N1 & 7) || (N2 & 7) || (lda & 7) || (ldb & 7) || lda < N1 || ldb < N2)
         return CWLT_ERR_ARG;
     const int S = cwlt_wgrad_splits(M, N1, N2);
+    if (S <= 0 || (S & 7)) return CWLT_ERR_ARG;     // the kernel's workgroup -> (XCD, slice, tile) map needs S % 8 == 0
     long mslice = (M + S - 1) / S;
     mslice = (mslice + 2 * wg::BK - 1) / (2 * wg::BK) * (2 * wg::BK);   // even number of BK steps
     hipStream_t st = (hipStream_t)stream;
