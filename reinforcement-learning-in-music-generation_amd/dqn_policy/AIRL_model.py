@@ -48,9 +48,10 @@ class LongFormer(CWLongformerBase):
             raise ValueError("score_in_groups needs a whole number of groups")
         means = []
         step = windows_per_pass - windows_per_pass % group
-        for s in range(0, n, step):
-            e = min(n, s + step)
-            means.append(self._encode(data[s:e], masks[s:e]).float().mean(dim=1))
+        with ops.frozen_weights():                 # one scoring call: the weight copies are refreshed once, not per pass
+            for s in range(0, n, step):
+                e = min(n, s + step)
+                means.append(self._encode(data[s:e], masks[s:e]).float().mean(dim=1))
         return self._classify_groups(torch.cat(means, 0), group)
 
     def _classify_groups(self, mean, group):

@@ -197,10 +197,14 @@ def train_graphs_enabled():
 
 def graph_adam(params, lr, **kw):
     """torch.optim.Adam as the reference constructs it; when training steps may be captured, `capturable=True`
-    with the learning rate held in a device tensor, so an LR scheduler's updates reach the captured step."""
+    with the learning rate held in a device tensor, so an LR scheduler's updates reach the captured step.
+    `fused=True` there: the capturable multi-tensor ("foreach") path divides every state tensor by 0-dim tensors one
+    parameter at a time (2 x 438 launches per PPO step, 14 % of the window-50 update's GPU time); the fused kernel
+    does the whole step in a few launches."""
     params = list(params)
     if train_graphs_enabled() and params and params[0].is_cuda:
-        return torch.optim.Adam(params, lr=torch.tensor(float(lr), device=params[0].device), capturable=True, **kw)
+        return torch.optim.Adam(params, lr=torch.tensor(float(lr), device=params[0].device), capturable=True,
+                                fused=True, **kw)
     return torch.optim.Adam(params, lr=lr, **kw)
 
 
@@ -261,8 +265,6 @@ class GraphedCall:
         for s, a in zip(static, args):
             s.copy_(a)
         graph.replay()
-        if self.grad:
-            weights_changed()       # the captured optimizer step moved the parameters without bumping their versions
         return out
 
 
@@ -273,21 +275,33 @@ class GraphedCall:
 # The f32 master weights are used in bf16 (and Q/K/V row-stacked) by every layer.  Casting them per call is seven
 # 1-4 MB copy kernels + two cat kernels per layer per forward: nothing at B*T = 524 288 rows, but a third of the GPU
 # time of the launch-bound RL steps (window 50: 108 such kernels per 12-layer trunk forward).  A ShadowSet keeps
-# persistent copies and refreshes ALL of them with one multi-tensor copy, and only when a parameter changed.
-_WEIGHTS_EPOCH = [0]      # bumped when parameters change behind autograd's back (replay of a captured optimizer step)
+# persistent copies and refreshes ALL of them with one multi-tensor copy per forward.
+#
+# The refresh is unconditional: nothing cheap says whether a parameter changed (fused optimizers and replays of a
+# captured optimizer step move parameters WITHOUT bumping autograd's version counters).  Only inside
+# `with ops.frozen_weights():` -- a scope in which the caller guarantees that no parameter changes, e.g. the loop
+# over buffer batches of one reward-scoring call -- is a set refreshed once and then reused.
+_FROZEN = [0]            # id of the innermost frozen_weights scope, 0 outside any
+_FROZEN_IDS = [0]
 
 
-def weights_changed():
-    _WEIGHTS_EPOCH[0] += 1
+class frozen_weights:
+    """Scope in which no parameter of any model changes: ShadowSets refresh at most once inside it."""
+
+    def __enter__(self):
+        self.prev = _FROZEN[0]
+        _FROZEN_IDS[0] += 1
+        _FROZEN[0] = _FROZEN_IDS[0]
+        return self
+
+    def __exit__(self, *exc):
+        _FROZEN[0] = self.prev
+        return False
 
 
 class ShadowSet:
     """`groups`: tuples of parameters; group i becomes ONE buffer of `dtype` with its members stacked along dim 0
-    (a single-member group is a plain cast).  `refresh()` -> list of buffers, up to date with the parameters.
-
-    Freshness is tracked by the parameters' autograd version counters (optimizer steps, copy_, load_state_dict bump
-    them) plus `weights_changed()` for graph replays.  While a hipGraph is being CAPTURED the copy is always
-    recorded, so that every replay re-derives the buffers from the then-current parameters."""
+    (a single-member group is a plain cast).  `refresh()` -> list of buffers, up to date with the parameters."""
 
     def __init__(self, groups, dtype):
         self.dtype = dtype
@@ -302,18 +316,18 @@ class ShadowSet:
                 self.src.append(p)
                 o += p.shape[0]
             self.bufs.append(buf)
-        self.tag = None
+        self.fresh_in = -1           # id of the frozen_weights scope the buffers were last refreshed in
 
     def matches(self, dtype, device):
         return self.dtype == dtype and self.device == device and all(p.device == device for p in self.src)
 
     def refresh(self):
-        capturing = torch.cuda.is_current_stream_capturing()
-        tag = (_WEIGHTS_EPOCH[0],) + tuple(p._version for p in self.src)
-        if capturing or tag != self.tag:
-            with torch.no_grad():
-                torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
-            self.tag = None if capturing else tag
+        scope = _FROZEN[0]
+        if scope and self.fresh_in == scope and not torch.cuda.is_current_stream_capturing():
+            return self.bufs
+        with torch.no_grad():
+            torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
+        self.fresh_in = scope if scope else -1
         return self.bufs
 
 

@@ -203,8 +203,9 @@ def test_graphed_ppo_update_policy_matches_eager(cuda, tmp_path, monkeypatch):
 
 def test_weight_shadows_follow_the_parameters(cuda, tmp_path, monkeypatch):
     """ops.ShadowSet (persistent bf16 copies of the master weights): an eager forward always computes with the current
-    parameters -- after an in-place update, after load_state_dict, after the replay of a captured optimizer step --
-    and two forwards before one backward (PPO's pattern) give the gradients of recomputed casts."""
+    parameters -- after an in-place update, after load_state_dict, after a FUSED optimizer step (which does not bump
+    autograd's version counters), after the replay of a captured optimizer step -- and two forwards before one
+    backward (PPO's pattern) give the gradients of recomputed casts."""
     monkeypatch.chdir(tmp_path)
     from rlmg_amd.dqn_policy import IRL_dqn_train as T, config, model
     old = _small(config.AgentConfig)
@@ -239,7 +240,28 @@ def test_weight_shadows_follow_the_parameters(cuda, tmp_path, monkeypatch):
             h2 = net.forward_hidden(x).float().clone()
         assert (h2 - h1).abs().max().item() > 1e-4 and torch.equal(h2, fresh_forward(net))
 
-        # captured optimizer step: parameters move without a version bump; GraphedCall reports it
+        # fused Adam moves the parameters without touching their version counters
+        opt = torch.optim.Adam(net.parameters(), lr=1e-2, fused=True)
+        net.train()
+        tgt0 = torch.stack([torch.randint(0, n, (2, 32), generator=g) for n in n_class], -1).to(cuda)
+        sum(net.train_step(x, tgt0, torch.ones(2, 32, device=cuda))).backward()
+        v0 = net.in_linear.weight._version
+        opt.step()
+        net.eval()
+        with torch.no_grad():
+            h3 = net.forward_hidden(x).float().clone()
+        assert (h3 - h2).abs().max().item() > 1e-3 and torch.equal(h3, fresh_forward(net)), net.in_linear.weight._version - v0
+        # inside ops.frozen_weights() the caller vouches that nothing changes: copies are refreshed once and reused
+        with ops.frozen_weights(), torch.no_grad():
+            a1 = net.forward_hidden(x).float().clone()
+            lin.weight.mul_(1.25)
+            a2 = net.forward_hidden(x).float().clone()
+        assert torch.equal(a1, a2)                                          # by contract: the stale copy
+        with torch.no_grad():
+            a3 = net.forward_hidden(x).float().clone()
+        assert (a3 - a1).abs().max().item() > 1e-4 and torch.equal(a3, fresh_forward(net))
+
+        # captured optimizer step: parameters move without a version bump
         monkeypatch.setattr(ops, "GRAPHS_ENABLED", True)
         monkeypatch.setattr(ops, "TRAIN_GRAPHS", True)
         agent = T.DQN(n_class, Pretrain=False)
