@@ -49,13 +49,20 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     const int l31 = lane & 31, hf = lane >> 5;
     // XCD-aware work mapping (speed only): workgroup ids are dealt round-robin over the 8 XCDs, so id % 8
     // labels the XCD.  All tiles of one token slice read the same A / B rows; giving a slice's tiles to ONE
-    // XCD lets those re-reads hit that XCD's L2 instead of HBM.  S (number of slices) is a multiple of 8.
+    // XCD lets those re-reads hit that XCD's L2 instead of HBM (used when the number of slices S is a multiple of 8).
     const int nt1 = (N1 + TM - 1) / TM, nt2 = (N2 + TN - 1) / TN;   // partial edge tiles allowed (N % 8 == 0)
     const int ntile = nt1 * nt2;
     const int id = blockIdx.x;
-    const int xcd = id & 7, idx = id >> 3;
-    const int slice = xcd + 8 * (idx / ntile);
-    const int tile = idx % ntile;
+    const int S = gridDim.x / ntile;                // the launcher's grid is exactly ntile * S workgroups
+    int slice, tile;
+    if (S & 7) {                                    // few token rows -> few slices: plain (slice, tile) order
+        slice = id / ntile;
+        tile = id - slice * ntile;
+    } else {
+        const int xcd = id & 7, idx = id >> 3;
+        slice = xcd + 8 * (idx / ntile);
+        tile = idx % ntile;
+    }
     const int t1 = tile / nt2, t2 = tile % nt2;
     const long m0 = (long)slice * mslice;
     const long m1 = min(M, m0 + mslice);
@@ -177,6 +184,10 @@ int cwlt_wgrad_splits(int64_t M, int N1, int N2) {
     s = s / 8 * 8;                              // ... in multiples of 8 (one slice group per XCD)
     if (s < 8) s = 8;
     if (s > 128) s = 128;
+    // few token rows (the RL updates: 1 500): a slice below ~256 rows is mostly padding, and every extra slice is
+    // another N1 x N2 f32 partial tile for the reduce kernel to read
+    const long by_rows = M / 256 > 0 ? M / 256 : 1;
+    if (s > by_rows) s = by_rows;
     return (int)s;
 }
 
@@ -189,7 +200,7 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
     if (N1 <= 0 || N2 <= 0 || (N1 & 7) || (N2 & 7) || (lda & 7) || (ldb & 7) || lda < N1 || ldb < N2)
         return CWLT_ERR_ARG;
     const int S = cwlt_wgrad_splits(M, N1, N2);
-    if (S <= 0 || (S & 7)) return CWLT_ERR_ARG;     // the kernel's workgroup -> (XCD, slice, tile) map needs S % 8 == 0
+    if (S <= 0) return CWLT_ERR_ARG;
     long mslice = (M + S - 1) / S;
     mslice = (mslice + 2 * wg::BK - 1) / (2 * wg::BK) * (2 * wg::BK);   // even number of BK steps
     hipStream_t st = (hipStream_t)stream;
