@@ -49,6 +49,11 @@ def test_argument_validation_without_gpu(built):
     assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 0, null) == 1001
     assert lib.cwlt_add_dropout_layernorm_fwd(null, null, null, null, null, null, null, null, 4, 512, 1e-5, 0.0, 0, null, 0, null) == 1001
     assert lib.cwlt_ln_blocks(65536) == 1024 and lib.cwlt_ln_blocks(1) == 1
+    # weight-gradient split counts: ~one workgroup per CU in multiples of 8 at training sizes, slices of >= 256 token
+    # rows at RL sizes (the caller sizes the partial-tile workspace from this)
+    assert lib.cwlt_wgrad_splits(524288, 2048, 512) == 16 and lib.cwlt_wgrad_splits(524288, 512, 512) == 64
+    assert lib.cwlt_wgrad_splits(1500, 2048, 512) == 5 and lib.cwlt_wgrad_splits(32, 256, 256) == 1
+    assert lib.cwlt_wgrad_splits(4096, 2048, 512) == 16
     assert lib.cwlt_sample_categorical(buf, (ctypes.c_int * 2)(5, 300), None, None, 2, 1, 305, 0, null, buf, null, 0, null) == 1001
     # generation step: an incomplete model description is refused before any launch
     m = built.DecodeModel()
