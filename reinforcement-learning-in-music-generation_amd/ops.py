@@ -299,6 +299,10 @@ class frozen_weights:
         return False
 
 
+def _no_shadow():
+    return None
+
+
 class ShadowSet:
     """`groups`: tuples of parameters; group i becomes ONE buffer of `dtype` with its members stacked along dim 0
     (a single-member group is a plain cast).  `refresh()` -> list of buffers, up to date with the parameters."""
@@ -320,6 +324,11 @@ class ShadowSet:
 
     def matches(self, dtype, device):
         return self.dtype == dtype and self.device == device and all(p.device == device for p in self.src)
+
+    def __reduce__(self):
+        # a cache, not state: copy.deepcopy(model) / torch.save(model) get None and rebuild it on first use (a copied
+        # set would have its views detached from its buffers)
+        return (_no_shadow, ())
 
     def refresh(self):
         scope = _FROZEN[0]

@@ -78,3 +78,28 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dp, f)
+
+
+def test_shadow_set_host_logic():
+    """ops.ShadowSet: stacked compute-dtype copies follow the parameters on every refresh, are reused only inside an
+    ops.frozen_weights() scope, and are dropped (not copied) by copy.deepcopy / pickling of the owning module."""
+    import copy
+    import pickle
+    import torch
+    from rlmg_amd import ops
+    q, k, b = (torch.nn.Parameter(torch.randn(4, 3)) for _ in range(3))
+    sh = ops.ShadowSet([(q, k), (b,)], torch.bfloat16)
+    w, bb = sh.refresh()
+    assert w.shape == (8, 3) and torch.equal(w[4:], k.detach().bfloat16()) and torch.equal(bb, b.detach().bfloat16())
+    with torch.no_grad():
+        k.mul_(2.0)
+    assert torch.equal(sh.refresh()[0][4:], k.detach().bfloat16())
+    with ops.frozen_weights():
+        sh.refresh()
+        with torch.no_grad():
+            k.mul_(2.0)
+        assert not torch.equal(sh.refresh()[0][4:], k.detach().bfloat16())      # reused, by contract
+    assert torch.equal(sh.refresh()[0][4:], k.detach().bfloat16())
+    holder = torch.nn.Module()
+    holder.q, holder.k, holder.b, holder._shadow = q, k, b, sh
+    assert copy.deepcopy(holder)._shadow is None and pickle.loads(pickle.dumps(sh)) is None
