@@ -332,7 +332,8 @@ class ShadowSet:
 
     def refresh(self):
         scope = _FROZEN[0]
-        if scope and self.fresh_in == scope and not torch.cuda.is_current_stream_capturing():
+        if scope and self.fresh_in == scope and not (self.device.type == "cuda"
+                                                     and torch.cuda.is_current_stream_capturing()):
             return self.bufs
         with torch.no_grad():
             torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
