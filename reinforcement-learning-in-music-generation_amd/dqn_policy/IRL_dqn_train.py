@@ -10,7 +10,6 @@ import os
 import sys
 import time
 
-import numpy as np
 import torch
 import torch.optim as optim
 

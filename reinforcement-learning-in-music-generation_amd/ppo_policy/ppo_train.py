@@ -13,7 +13,6 @@ import time
 
 import torch
 import torch.nn.functional as F
-import torch.optim as optim
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if _ROOT not in sys.path:

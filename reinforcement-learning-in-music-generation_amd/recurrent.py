@@ -13,7 +13,6 @@ single-launch decode step across all 12 layers is the natural next step.
 """
 import torch
 import torch.nn as nn
-import torch.nn.functional as F
 
 from . import ops
 
