@@ -41,18 +41,24 @@ class _FusedPlan:
         enc = model.transformer_encoder
         f32 = lambda t: t.detach().float().contiguous()
         self.keep = []
+        self.packed = []           # (buffer, source tensors): row-stacked copies, re-filled in place by refresh()
 
         def P(t):
-            t = f32(t)
+            t = f32(t)             # an f32 contiguous parameter is used in place: optimizer steps are seen directly
             self.keep.append(t)
             return _lib.dev(t).value
+
+        def PACK(ts):
+            buf = torch.cat([f32(t) for t in ts], 0)
+            self.packed.append((buf, list(ts)))
+            return _lib.dev(buf).value
 
         layers = (_lib.DecodeLayer * len(enc.layers))()
         for i, (L, (S, Z)) in enumerate(zip(enc.layers, memory)):
             at = L.attention
             d = layers[i]
-            d.wqkv = P(torch.cat([at.query_projection.weight, at.key_projection.weight, at.value_projection.weight], 0))
-            d.bqkv = P(torch.cat([at.query_projection.bias, at.key_projection.bias, at.value_projection.bias], 0))
+            d.wqkv = PACK([at.query_projection.weight, at.key_projection.weight, at.value_projection.weight])
+            d.bqkv = PACK([at.query_projection.bias, at.key_projection.bias, at.value_projection.bias])
             d.wo, d.bo = P(at.out_projection.weight), P(at.out_projection.bias)
             d.ln1_w, d.ln1_b = P(L.norm1.weight), P(L.norm1.bias)
             d.w1, d.b1 = P(L.linear1.weight), P(L.linear1.bias)
@@ -84,8 +90,8 @@ class _FusedPlan:
             if enc.norm.eps != enc.layers[0].norm1.eps:
                 raise RuntimeError("decode step needs one LayerNorm eps for the whole encoder")
             m.lnf_w, m.lnf_b = P(enc.norm.weight), P(enc.norm.bias)
-        m.w_heads = P(torch.cat([h.weight for h in heads], 0))
-        m.b_heads = P(torch.cat([h.bias for h in heads], 0))
+        m.w_heads = PACK([h.weight for h in heads])
+        m.b_heads = PACK([h.bias for h in heads])
         self.model = m
         per_song = lib.cwlt_decode_workspace_floats(ctypes.byref(m))
         if per_song <= 0:
@@ -96,6 +102,12 @@ class _FusedPlan:
         self.hidden = torch.zeros((n_songs, m.d_model), dtype=torch.float32, device=dev)
         self.logits = torch.zeros((n_songs, m.n_logits), dtype=torch.float32, device=dev)
         self.n_songs = n_songs
+
+    def refresh(self):
+        """Re-fill the row-stacked copies from the parameters, in place (pointers, and a captured graph, stay valid)."""
+        with torch.no_grad():
+            for buf, srcs in self.packed:
+                torch.cat([t.detach().float() for t in srcs], 0, out=buf)
 
     def step(self, tok):
         from . import _lib
@@ -148,14 +160,19 @@ class DecodeSession:
         self.n_steps = 0
 
     def _weights_tag(self):
-        return tuple((p.data_ptr(), p._version) for p in self.model.parameters())
+        return tuple(p.data_ptr() for p in self.model.parameters())
 
     def reset(self):
-        """Start new songs: zero the state.  The packed weights and the captured graph are kept unless a parameter
-        changed since they were built (optimizer step, load_state_dict)."""
+        """Start new songs: zero the state and bring the step's weights up to date.  Unstacked f32 parameters are
+        read in place; the row-stacked copies (Q/K/V, heads) are re-filled in place -- unconditionally: version
+        counters do not see fused optimizers -- so the captured graph stays valid.  Only parameters that moved to
+        other storage (.to(), load_state_dict(assign=True)) force a rebuild."""
         self._state.zero_()
-        if self.fused and self._plan is not None and self._plan.tag != self._weights_tag():
-            self._plan, self._graph = None, None
+        if self.fused and self._plan is not None:
+            if self._plan.tag != self._weights_tag():
+                self._plan, self._graph = None, None
+            else:
+                self._plan.refresh()
         self.n_steps = 0
 
     def _device_step(self):
