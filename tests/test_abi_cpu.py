@@ -103,3 +103,21 @@ def test_shadow_set_host_logic():
     holder = torch.nn.Module()
     holder.q, holder.k, holder.b, holder._shadow = q, k, b, sh
     assert copy.deepcopy(holder)._shadow is None and pickle.loads(pickle.dumps(sh)) is None
+
+
+def test_public_header_is_plain_c(tmp_path):
+    """include/cwlt.h is the contract for non-Python hosts: it must compile as C99 (and as C++) on its own, and a C
+    host linking the library must resolve the symbols it declares."""
+    import shutil
+    import subprocess
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    src = tmp_path / "host.c"
+    src.write_text('#include "cwlt.h"\n'
+                   "int main(void) { cwlt_decode_model m; cwlt_decode_layer l; (void)m; (void)l;\n"
+                   "  return cwlt_abi_version() > 0 && cwlt_ln_blocks(1) == 1 ? 0 : 1; }\n")
+    inc = os.path.join(ROOT, "include")
+    for cmd in (["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-I", inc, str(src)],
+                ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr
