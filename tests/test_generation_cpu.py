@@ -157,3 +157,53 @@ def test_fast_samplers_equal_a_line_by_line_restatement():
         state_got = np.random.get_state()[1], np.random.get_state()[2]
         assert got == want, (trial, n, t, p)
         assert state_got[1] == state_want[1] and (state_got[0] == state_want[0]).all()
+
+
+def test_inference_from_scratch_loop_semantics_with_a_scripted_session():
+    """Host logic of generation.inference_from_scratch (testing-no-type-cp.py:126-179) without a GPU: a scripted
+    session feeds logits that make the samplers deterministic.  The song starts with the Bar token, every sampled
+    token is appended BEFORE the bar check, and the loop stops with the token that opens bar `bar_cond`."""
+    from rlmg_amd import data, generation
+    w2e = {k: v for k, v in data.synthetic_cp_vocabulary().items() if k != "type"}
+    n_class = [len(w2e[k]) for k in w2e]
+    script = [2, 5, 1, 7, 7, 1, 3, 1, 9]            # bar-beat ids the "model" wants next; 1 == 'Bar'
+
+    class Scripted:
+        n_token = n_class
+        use_graph = False
+
+        def __init__(self):
+            self.fed = []
+
+        def reset(self):
+            self.fed = []
+
+        def step(self, ids):
+            self.fed.append(np.asarray(ids).copy())
+            t = len(self.fed) - 1
+            logits = np.full(sum(n_class), -50.0, dtype=np.float32)
+            o = 0
+            for a, n in enumerate(n_class):
+                want = script[min(t, len(script) - 1)] if a == 2 else (t + a) % n
+                logits[o + want] = 50.0
+                o += n
+            return logits
+
+        def split(self, logits):
+            outs, o = [], 0
+            for n in n_class:
+                outs.append(logits[o:o + n])
+                o += n
+            return outs
+
+    np.random.seed(0)
+    sess = Scripted()
+    song = generation.inference_from_scratch(None, w2e, bar_cond=3, session=sess)
+    # bars: the initial Bar token counts as bar 1; script positions 2 and 5 are Bars -> stop after the second of them
+    assert song[0].tolist() == generation.INIT_CW[0].tolist()
+    assert song[1:, 2].tolist() == script[:6] and len(song) == 7
+    assert [r.tolist() for r in sess.fed] == [r.tolist() for r in song]            # every token is fed back, last too
+    assert song[3].tolist() == [2 % n_class[0], 3 % n_class[1], 1, 5 % n_class[3], 6 % n_class[4], 7 % n_class[5]]
+    np.random.seed(0)
+    capped = generation.inference_from_scratch(None, w2e, bar_cond=99, max_tokens=5, session=Scripted())
+    assert len(capped) == 5
