@@ -9,25 +9,32 @@ buckets (default 32 MiB) beat many small ones.  With world_size == 1 the same fl
 fused gradient-norm clip, and nothing is communicated.
 
 Two ways a gradient arrives: through autograd (post-accumulate hook) or written straight into the bucket by a
-layer backward (`ops.deliver_grads`, which then calls the parameter's `_cwlt_ready` callback).  Either way a
-parameter must report exactly once per backward.  Steps that run SEVERAL backward passes before the
-optimizer step (gradient accumulation, e.g. PPO.update_rollouts) set `defer = True`: nothing is launched from
-the callbacks and `finish()` reduces every bucket once, after the last backward.
+layer backward (`ops.deliver_grads`, which then calls the parameter's `_cwlt_ready` callback).
+
+Two modes:
+  overlap=True  (the pretrain step: ONE forward, ONE backward): every parameter reports exactly once per backward and
+                a bucket's all-reduce starts when its last parameter has reported.  A parameter that reports a SECOND
+                time before `zero_grad()` raises: a bucket may already be on the wire with only part of its gradient
+                (a network run twice in one step delivers each encoder-layer gradient once per forward pass).
+  overlap=False (`defer`; every RL step: DQN.update and PPO's inner step run the trainable net twice -- the TD /
+                `select_udpate` pass and `train_step` -- and PPO.update_rollouts accumulates over rollout groups):
+                nothing is launched from the callbacks; `finish()` reduces every bucket once, after the last
+                backward.  The RL updates are small next to their all-reduce-free compute, so nothing is lost.
 """
 import torch
 import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "pending", "work")
+    __slots__ = ("flat", "params", "seen", "work", "launched")
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, params
-        self.pending, self.work = len(params), None
+        self.seen, self.work, self.launched = set(), None, False
 
 
 class GradSync:
-    def __init__(self, params, bucket_bytes=32 << 20, group=None):
+    def __init__(self, params, bucket_bytes=32 << 20, group=None, overlap=True):
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
         params = [p for p in params if p.requires_grad]
@@ -43,7 +50,7 @@ class GradSync:
                 cur, cur_n = [], 0
         if cur:
             self._close(cur)
-        self.defer = False
+        self.defer = not overlap
         self._by_param = {}
         for b in self.buckets:
             for p in b.params:
@@ -61,6 +68,7 @@ class GradSync:
         self.buckets.append(_Bucket(flat, list(params)))
 
     def _launch(self, b):
+        b.launched = True
         if self.world > 1:
             b.flat.div_(self.world)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
@@ -69,15 +77,20 @@ class GradSync:
         if self.defer:
             return
         b = self._by_param[p]
-        b.pending -= 1
-        if b.pending == 0:
+        if id(p) in b.seen:
+            raise RuntimeError(
+                "GradSync(overlap=True): a parameter reported its gradient twice in one step (the network ran more "
+                "than one forward pass before backward, or backward ran twice).  Its bucket may already be in flight "
+                "with a partial gradient -- build the GradSync with overlap=False (or set defer) for such steps")
+        b.seen.add(id(p))
+        if len(b.seen) == len(b.params):
             self._launch(b)
 
     def zero_grad(self):
         """Replaces net.zero_grad(): keeps the .grad views, zeroes the flat storage."""
         for b in self.buckets:
             b.flat.zero_()
-            b.pending, b.work = len(b.params), None
+            b.seen, b.work, b.launched = set(), None, False
             o = 0
             for p in b.params:       # re-attach in case an optimizer / user dropped the view
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + 4 * o:
@@ -87,7 +100,7 @@ class GradSync:
     def finish(self):
         """Wait for every bucket (launching those whose parameters never received a gradient)."""
         for b in self.buckets:
-            if b.work is None and (b.pending > 0 or self.defer):
+            if not b.launched:
                 self._launch(b)
         for b in self.buckets:
             if b.work is not None:

@@ -16,6 +16,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import dist as rdist  # noqa: E402
 
 try:
     from AIRL_model import LongFormer
@@ -45,6 +46,9 @@ class RewardDiscri(nn.Module):
         self.init_lr = 0.001
         self.epoch_disc = 5
         self.batch_size = 100
+        # data parallel: flat gradient buckets, reduced once per batch in finish() (the batch runs the discriminator
+        # three times -- expert score, token CE, agent score -- before its one backward: overlap=False)
+        self.sync_disc = rdist.GradSync(self.disc_model.parameters(), overlap=False)
         self.optim_disc = optim.Adam(self.disc_model.parameters(), lr=self.init_lr)
         self.sched_disc = torch.optim.lr_scheduler.StepLR(self.optim_disc, step_size=10, gamma=0.1)
         self.reward_path = "./exp/IRL_reward.pickle"
@@ -58,7 +62,10 @@ class RewardDiscri(nn.Module):
 
     def _maybe_reload(self):
         """The reference re-reads ./ckpt/disc_IRL.pt from disk on EVERY call (AIRL.py:73); here the file is
-        re-read only when it changed.  A missing file keeps the current weights (the reference would raise)."""
+        re-read only when it changed.  A missing file keeps the current weights where the reference's torch.load
+        would raise FileNotFoundError (listed under "differences" in INTEGRATION.md): IRL_dqn_train.py only ever
+        calls update_disc(train=False), which never writes that file, so the reference's loop cannot get past its
+        first scoring call without a checkpoint prepared by hand."""
         p = self.IRL_ckpt_path
         if os.path.exists(p):
             m = os.path.getmtime(p)
@@ -105,7 +112,7 @@ class RewardDiscri(nn.Module):
                 sums = torch.zeros(4, device="cuda")
                 for idx in range(n_batch):
                     s, e = idx * bs, (idx + 1) * bs
-                    self.optim_disc.zero_grad()
+                    self.sync_disc.zero_grad()
                     st_exp = exp_state_action[s:e].long().cuda()
                     m_st = mask_states[s:e].long().cuda()
                     m_nx = mask_next_states[s:e].long().cuda()
@@ -119,13 +126,24 @@ class RewardDiscri(nn.Module):
                     agent_bce = self.BCE_criterion(agent_logits, agent_label)
                     global_loss = exp_bce + (agent_bce + ce)
                     global_loss.backward()
+                    self.sync_disc.finish()                  # world > 1: mean gradient over ranks (RCCL)
                     self.optim_disc.step()
                     self.sched_disc.step()
                     sums += torch.stack([exp_bce.detach(), agent_bce.detach(), ce.detach(), global_loss.detach()])
-                if epoch % 5 == 0 and n_batch:
+                world = self.sync_disc.world
+                if world > 1:
+                    # replicas saw different batches: average the BatchNorm running statistics so that every rank
+                    # holds (and rank 0 saves) the same discriminator
+                    for buf in self.disc_model.buffers():
+                        if buf.dtype.is_floating_point:
+                            torch.distributed.all_reduce(buf)
+                            buf.div_(world)
+                if epoch % 5 == 0 and n_batch and (world == 1 or torch.distributed.get_rank() == 0):
                     os.makedirs(os.path.dirname(self.IRL_ckpt_path) or ".", exist_ok=True)
                     torch.save({"epoch": self.epoch_disc, "model_state_dict": self.disc_model.state_dict(),
                                 "optimizer_state_dict": self.optim_disc.state_dict()}, self.IRL_ckpt_path)
+                if world > 1:
+                    torch.distributed.barrier()              # the checkpoint is on disk before any rank reloads it
                 if n_batch:
                     e_l, a_l, c_l, g_l = (sums / n_batch).tolist()
                     self.last_losses.append({"expert": e_l, "agent": a_l, "ce": c_l, "global": g_l})

@@ -80,7 +80,9 @@ class DQN(object):
         self.target_net.train()
         self.agent_buffer = AgentMemory()
         self.expert_buffer = ExpertMemory()
-        self.sync = rdist.GradSync(self.eval_net.parameters())           # flat grads; RCCL all-reduce if world > 1
+        # flat gradient buckets; RCCL all-reduce if world > 1.  overlap=False: update() runs eval_net twice before one
+        # backward (TD pass + train_step), so every encoder gradient is delivered twice -- reduce once, in finish()
+        self.sync = rdist.GradSync(self.eval_net.parameters(), overlap=False)
         self.optim = ops.graph_adam(self.eval_net.parameters(), lr=init_lr)
         self.scheduler = optim.lr_scheduler.MultiStepLR(self.optim, milestones=[20, 40], gamma=0.1)
         self.target_count = 0

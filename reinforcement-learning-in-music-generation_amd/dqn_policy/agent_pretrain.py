@@ -88,21 +88,27 @@ def train(n_epoch=None, compute_dtype=torch.float32, log=print):
                 saver_agent.add_summary("batch loss", loss.item())
         runtime = time.time() - start_time
         epoch_loss = acc_loss / max(1, num_batch)
+        if world > 1:
+            # every rank must take the same stop / checkpoint-band decision (the reference is one process): use the
+            # mean over ranks of the per-rank epoch losses
+            t = torch.tensor([epoch_loss], dtype=torch.float64, device="cuda")
+            torch.distributed.all_reduce(t)
+            epoch_loss = t.item() / world
         if saver_agent:
             saver_agent.add_summary("epoch loss", epoch_loss)
             saver_agent.add_summary("epoch each loss", "{:04f}, {:04f}, {:04f}, {:04f}, {:04f}, {:04f}\r".format(
                 *(acc_losses / max(1, num_batch))))
         log("Epoch: {}/{} | Loss: {} | time: {}".format(epoch, n_epoch, epoch_loss,
                                                         str(datetime.timedelta(seconds=runtime))))
+        if epoch_loss <= 0.05:                     # agent_pretrain.py:611-613 -- on EVERY rank (same epoch_loss)
+            log("Finished")
+            return epoch_loss
         if rank == 0:
             os.makedirs("./ckpt", exist_ok=True)
             if 0.4 < epoch_loss <= 0.8:
                 name = "trainloss_" + str(int(epoch_loss * 10) * 10) + ".pt"
             elif 0.05 < epoch_loss <= 0.40:
                 name = "trainloss_" + str(int(epoch_loss * 100)) + ".pt"
-            elif epoch_loss <= 0.05:
-                log("Finished")
-                return epoch_loss
             else:
                 name = "trainloss_" + str(int(epoch_loss * 100)) + "_high.pt"
             torch.save({"epoch": n_epoch, "model_state_dict": net.state_dict(),

@@ -80,8 +80,11 @@ class PPO(object):
         self.critic_net.train()          # eval_net is left in its default train() mode, as in the reference (:235)
         self.agent_buffer = AgentMemory()
         self.expert_buffer = ExpertMemory()
-        self.actor_sync = rdist.GradSync(self.actor_net.parameters())     # RCCL all-reduce when world > 1
-        self.critic_sync = rdist.GradSync(self.critic_net.parameters())
+        # RCCL all-reduce when world > 1.  overlap=False: every PPO step runs the actor twice before one backward
+        # (select_udpate + train_step) or accumulates several backward passes (update_rollouts), so the buckets
+        # are reduced once per step, in finish()
+        self.actor_sync = rdist.GradSync(self.actor_net.parameters(), overlap=False)
+        self.critic_sync = rdist.GradSync(self.critic_net.parameters(), overlap=False)
         self.actor_optim = ops.graph_adam(self.actor_net.parameters(), lr=init_lr)
         self.critic_optim = ops.graph_adam(self.critic_net.parameters(), lr=init_lr)
         self.target_count = self.cnt_update = 0
@@ -172,8 +175,7 @@ class PPO(object):
         back = torch.arange(NA, device=dev)
         self.actor_sync.zero_grad()
         self.critic_sync.zero_grad()
-        # several backward passes accumulate into the buckets: reduce across ranks once, in finish()
-        self.actor_sync.defer = self.critic_sync.defer = True
+        # several backward passes accumulate into the buckets: reduced across ranks once, in finish() (overlap=False)
         for r0 in range(0, R, group):
             k = min(group, R - r0)
             st = states[:, r0:r0 + k].transpose(0, 1).reshape(k * E, W, 6)              # rollout-major
@@ -198,7 +200,6 @@ class PPO(object):
             (critic_loss / R).backward()
         self.actor_sync.finish()
         self.critic_sync.finish()
-        self.actor_sync.defer = self.critic_sync.defer = False
         self.actor_optim.step()
         self.critic_optim.step()
 

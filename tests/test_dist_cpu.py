@@ -59,6 +59,35 @@ def _worker(rank, world, port, out):
     ops.deliver_grads(tuple(zip(ps[3:], gs[3:])))
     sync.finish()
     res["direct"] = [p.grad.clone() for p in net.parameters()]
+    # A step that runs the network TWICE before one backward (DQN.update: TD pass + train_step; PPO's inner step:
+    # select_udpate + train_step) delivers every directly-written gradient twice.  With the default overlap=True
+    # sync that must fail loudly (a bucket would go on the wire after the first pass's gradients only) ...
+    g1 = torch.autograd.grad(net(xs[:2]).pow(2).sum() / 4, ps)
+    g2 = torch.autograd.grad(net(xs[2:]).pow(2).sum() / 4, ps)
+    sync.zero_grad()
+    ops.deliver_grads(tuple(zip(ps, g1)))
+    try:
+        ops.deliver_grads(tuple(zip(ps, g2)))
+        res["double_raises"] = False
+    except RuntimeError as e:
+        res["double_raises"] = "twice" in str(e)
+    sync.finish()                                        # drain whatever was launched before the error
+    # ... and with overlap=False (what DQN / PPO / RewardDiscri build) the two deliveries accumulate and finish()
+    # reduces once: equal to the single-process gradient
+    net2 = _model()
+    sync2 = rdist.GradSync(list(net2.parameters()), bucket_bytes=256, overlap=False)
+    ps2 = list(net2.parameters())
+    for step in range(2):
+        h1 = torch.autograd.grad(net2(xs[:2]).pow(2).sum() / 4, ps2)
+        h2 = torch.autograd.grad(net2(xs[2:]).pow(2).sum() / 4, ps2)
+        sync2.zero_grad()
+        ops.deliver_grads(tuple(zip(ps2[:3], h1[:3])))   # pass 1, layer by layer
+        ops.deliver_grads(tuple(zip(ps2[3:], h1[3:])))
+        ops.deliver_grads(tuple(zip(ps2[:3], h2[:3])))   # pass 2
+        ops.deliver_grads(tuple(zip(ps2[3:], h2[3:])))
+        assert all(b.work is None and not b.launched for b in sync2.buckets)   # nothing on the wire before finish()
+        sync2.finish()
+    res["double"] = [p.grad.clone() for p in net2.parameters()]
     torch.save(res, out % rank)
     dist.barrier()
     dist.destroy_process_group()
@@ -79,7 +108,8 @@ def test_gradsync_world2_matches_single_process(tmp_path):
     for a, b, c in zip(r0["grads"], r1["grads"], ref):
         assert torch.allclose(a, b, atol=0, rtol=0)
         assert torch.allclose(a, c, atol=1e-6)
-    for key in ("accum", "direct"):
+    assert r0["double_raises"] is True and r1["double_raises"] is True
+    for key in ("accum", "direct", "double"):
         for a, b, c in zip(r0[key], r1[key], ref):
             assert torch.allclose(a, b, atol=0, rtol=0), key
             assert torch.allclose(a, c, atol=1e-6), key

@@ -152,16 +152,61 @@ def test_greedy_ids_bit_exact_vs_oracle(cuda):
     assert torch.equal(ids.cpu(), ids_ref)
 
 
-def test_bf16_mode_tracks_fp32(cuda):
+# bf16 mode against the fp32 oracle ---------------------------------------------------------------------------------
+# Error model for the bound below.  In bf16 mode every activation tensor that crosses HBM is rounded to 8 significant
+# bits: relative error uniform in +-2^-9, rms u = 2^-9 / sqrt(3) = 1.13e-3 per rounding.  One encoder layer stores 10
+# such tensors on the forward path (qkv, attention out, out-proj, s1, x1, h, g, ffn out, s2, layer out) and about as
+# many on the backward path; 12 layers + embedding / in_linear / positional encoding / final norm / logits give
+# n ~ 2 * (12 * 10 + 5) = 250 roundings between the tokens and a parameter gradient, plus the bf16 rounding of the
+# GEMM weights (same u, once per use).  Independent relative perturbations of rms u accumulate as a random walk:
+# expected norm-wise relative error of a gradient tensor ~ sqrt(n) * u = sqrt(250) * 1.13e-3 = 1.8e-2 (first order:
+# post-LN renormalises every layer, so the perturbations do not grow geometrically).  The test allows 4x that in
+# the L2 norm per tensor -- BF16_GRAD_REL = 7e-2 -- plus, for tensors whose own gradient is tiny next to the model's
+# (cancellation: key-projection biases), the same fraction of the model-wide RMS gradient norm per tensor.
+BF16_GRAD_REL = 4 * (2 * (12 * 10 + 5)) ** 0.5 * 2.0 ** -9 / 3 ** 0.5
+
+
+def test_repo_dims_bf16_train_step_grads_match_fp32_oracle(cuda):
+    """BASELINE configs[1]'s own shapes in the benched dtype: repo dims, T = 1024, B = 2, bf16 storage; losses and
+    EVERY parameter gradient against the fp32 CPU oracle on the same tokens (dropout off so both are deterministic)."""
     n_class = [56, 135, 18, 87, 18, 25]
     net = _dqn_model((512, 12, 8), n_class, 51, cuda)
+    ref = fill_params(cw_model.CWLinearTransformer(n_class, 512, 12, 8, variant="dqn"), seed=51).eval()
+    B, T = 2, 1024
     g = torch.Generator().manual_seed(10)
-    x = torch.stack([torch.randint(0, n, (2, 128), generator=g) for n in n_class], -1).to(cuda)
-    y = torch.stack([torch.randint(0, n, (2, 128), generator=g) for n in n_class], -1).to(cuda)
-    mask = torch.ones(2, 128, device=cuda)
-    l32 = torch.stack(net.train_step(x, y, mask))
+    x = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1)
+    y = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1)
+    mask = torch.ones(B, T)
+    mask[1, 900:] = 0
+    torch.set_num_threads(max(1, min(16, os.cpu_count() or 1)))
+    lr = ref.train_step(x, y, mask)
+    (sum(lr) / 6).backward()
     net.compute_dtype = torch.bfloat16
-    l16 = torch.stack(net.train_step(x, y, mask))
-    (l16.sum() / 6).backward()
-    assert (l32 - l16).abs().max().item() < 0.05
-    assert all(torch.isfinite(p.grad).all() for n_, p in net.named_parameters() if p.grad is not None)
+    lg = net.train_step(x.to(cuda), y.to(cuda), mask.to(cuda))
+    (sum(lg) / 6).backward()
+    l16, l32 = np.array([l.item() for l in lg]), np.array([l.item() for l in lr])
+    # a loss is a mean over 2 000 tokens of nll values that each carry the logits' relative error
+    assert np.abs(l16 - l32).max() <= BF16_GRAD_REL * np.abs(l32).max(), (l16, l32)
+    pr = dict(ref.named_parameters())
+    norms = {n_: pr[n_].grad.double().norm().item() for n_, p in net.named_parameters() if p.grad is not None}
+    rms_norm = (sum(v * v for v in norms.values()) / len(norms)) ** 0.5
+    rows, worst = [], 0.0
+    for name, p in net.named_parameters():
+        if name.startswith("project_concat_type"):
+            assert p.grad is None
+            continue
+        assert p.grad.dtype == torch.float32 and torch.isfinite(p.grad).all(), name
+        d = (p.grad.detach().double().cpu() - pr[name].grad.double()).norm().item()
+        rel = d / max(norms[name], 1e-30)
+        cos = torch.nn.functional.cosine_similarity(p.grad.detach().double().cpu().flatten(),
+                                                    pr[name].grad.double().flatten(), dim=0).item()
+        rows.append((name, norms[name], d, rel, cos))
+        worst = max(worst, d / (norms[name] + rms_norm))
+        assert d <= BF16_GRAD_REL * (norms[name] + rms_norm), (name, d, norms[name], rms_norm)
+    out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
+    if os.path.isdir(out_dir):
+        with open(os.path.join(out_dir, "bf16_grad_errors.txt"), "w") as f:
+            f.write("bound %.4f  rms tensor norm %.4e  losses bf16 %s fp32 %s\n" % (BF16_GRAD_REL, rms_norm, l16, l32))
+            for r in rows:
+                f.write("%-70s |g| %.4e  |d| %.4e  rel %.4e  cos %.6f\n" % r)
+    print("worst bf16 gradient error / (own norm + rms norm): %.4f (bound %.4f)" % (worst, BF16_GRAD_REL))
