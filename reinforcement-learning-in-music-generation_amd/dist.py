@@ -26,11 +26,11 @@ import torch.distributed as dist
 
 
 class _Bucket:
-    __slots__ = ("flat", "params", "seen", "work", "launched")
+    __slots__ = ("flat", "params", "seen", "n_seen", "work", "launched")
 
     def __init__(self, flat, params):
         self.flat, self.params = flat, params
-        self.seen, self.work, self.launched = set(), None, False
+        self.seen, self.n_seen, self.work, self.launched = set(), 0, None, False
 
 
 class GradSync:
@@ -55,8 +55,8 @@ class GradSync:
         for b in self.buckets:
             for p in b.params:
                 self._by_param[p] = b
-                p.register_post_accumulate_grad_hook(self._on_grad)
-                p._cwlt_ready = self._on_grad          # called by ops.deliver_grads after a direct write
+                p.register_post_accumulate_grad_hook(self._on_hook)
+                p._cwlt_ready = self._on_ready         # called by ops.deliver_grads after a direct write
 
     def _close(self, params):
         n = sum(p.numel() for p in params)
@@ -73,24 +73,37 @@ class GradSync:
             b.flat.div_(self.world)
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
-    def _on_grad(self, p):
-        if self.defer:
-            return
+    def _report(self, p, direct):
+        # A directly delivered gradient reports through `_cwlt_ready`; autograd then still runs the parameter's
+        # AccumulateGrad node with an undefined gradient (the layer backward returned None for it) and, on this
+        # PyTorch, fires the post-accumulate hook as well: that ONE echo per direct delivery is expected and ignored.
         b = self._by_param[p]
-        if id(p) in b.seen:
+        key = (id(p), direct)
+        if key in b.seen:
             raise RuntimeError(
                 "GradSync(overlap=True): a parameter reported its gradient twice in one step (the network ran more "
                 "than one forward pass before backward, or backward ran twice).  Its bucket may already be in flight "
                 "with a partial gradient -- build the GradSync with overlap=False (or set defer) for such steps")
-        b.seen.add(id(p))
-        if len(b.seen) == len(b.params):
+        b.seen.add(key)
+        if not direct and (id(p), True) in b.seen:
+            return                                     # echo of a direct delivery
+        b.n_seen += 1
+        if b.n_seen == len(b.params):
             self._launch(b)
+
+    def _on_hook(self, p):
+        if not self.defer:
+            self._report(p, False)
+
+    def _on_ready(self, p):
+        if not self.defer:
+            self._report(p, True)
 
     def zero_grad(self):
         """Replaces net.zero_grad(): keeps the .grad views, zeroes the flat storage."""
         for b in self.buckets:
             b.flat.zero_()
-            b.seen, b.work, b.launched = set(), None, False
+            b.seen, b.n_seen, b.work, b.launched = set(), 0, None, False
             o = 0
             for p in b.params:       # re-attach in case an optimizer / user dropped the view
                 if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + 4 * o:

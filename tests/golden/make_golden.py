@@ -268,8 +268,171 @@ def dqn_generation_small():
     config.AgentConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
 
 
+def _import_reference_ppo_train():
+    """/root/reference/ppo_policy/ppo_train.py, unmodified, on CPU (`config.device` falls back to cpu, config.py:11).
+    Beside `model` / `config` it imports wandb (absent here; every call to it is commented out in the file), tqdm and
+    matplotlib (both present): wandb gets an empty placeholder module that exists only inside this generator."""
+    import types
+    config, model = _import_reference("ppo_policy")
+    sys.modules.setdefault("wandb", types.ModuleType("wandb"))
+    sys.modules.pop("ppo_train", None)
+    path = os.path.join(REF, "ppo_policy")
+    sys.path.insert(0, path)
+    try:
+        pt = importlib.import_module("ppo_train")
+    finally:
+        sys.path.remove(path)
+    return config, model, pt
+
+
+def ppo_rl_small():
+    """The reference's own PPO class and buffers (ppo_policy/ppo_train.py:69-417) driven exactly as its main loop
+    drives them (:460-506) for one song: 30 env steps (choose_action -> next_state = cat(state[:25], action) ->
+    critic value -> reward model -> store_transition x2), then calculate_returns / calculate_advantages,
+    select_udpate, and ONE inner step of update_policy.  Small nets (128 / 2 / 2), name-keyed fills, all three nets in
+    eval() so that the record is deterministic (the reference rolls out with dropout live).  Also: ring overwrite and
+    seeded sampling of AgentMemory / ExpertMemory with BUFFER_SIZE patched to 8."""
+    config, model, pt = _import_reference_ppo_train()
+    small = {"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2}
+    config.ActorConfig.update(small)
+    config.CriticConfig.update(small)
+    config.DiscriConfig.update(small)
+    n_token = [49, 19, 19, 89, 67, 25]
+    import contextlib
+    import io
+    with contextlib.redirect_stdout(io.StringIO()):
+        agent = pt.PPO(n_token, Pretrain=False)
+    fill_params(agent.actor_net, seed=21).eval()
+    fill_params(agent.critic_net, seed=22).eval()
+    fill_params(agent.eval_net, seed=31).eval()
+    dev = pt.device
+    gen = torch.Generator().manual_seed(2468)
+    E, W, NA = pt.EPISODES, pt.WINDOW_SIZE, pt.N_ACTIONS
+    L = E + 50 + W + 4
+    train_x = _tokens(gen, (W,), n_token)
+    expert_x = _tokens(gen, (L,), n_token)
+    train_mask = torch.ones(L)
+    train_mask[70:] = 0
+    out = {"n_token": np.array(n_token), "state0": train_x.numpy(), "expert_x": expert_x.numpy(),
+           "train_mask": train_mask.numpy()}
+    # ---- rollout, ppo_train.py:467-496 ----
+    pt.AgentBuffer, pt.ExpertBuffer, pt.Agent = pt.AgentMemory(), pt.ExpertMemory(), agent
+    state_x = train_x
+    acts, logps, vals, rews = [], [], [], []
+    with torch.no_grad():
+        for num in range(E):
+            Expert_state = expert_x[num: num + W]
+            Expert_next_state = expert_x[num + 50: num + 50 + W]
+            Expert_reward = torch.tensor(1.0).float().to(dev)
+            Expert_done = torch.tensor(0).long().to(dev)
+            Expert_mask_state = train_mask[num: num + W]
+            Expert_mask_nextstate = train_mask[num + 1: num + 1 + W]
+            done = torch.tensor(0).long().to(dev)
+            action, log_prob_res = agent.choose_action(state_x.unsqueeze(0))
+            next_state = torch.cat((state_x[:NA, :], action), dim=0)
+            state_x = next_state
+            value_state = agent.critic_net.value_produce(state_x.unsqueeze(0))
+            agent_reward = agent.eval_net.token_forward(state_x.unsqueeze(0), Expert_state, Expert_mask_state.unsqueeze(0))
+            pt.AgentBuffer.store_transition(state_x, action, log_prob_res, value_state, agent_reward, next_state, done)
+            pt.ExpertBuffer.store_transition(Expert_state, action, Expert_reward, Expert_next_state, Expert_done,
+                                             Expert_mask_state, Expert_mask_nextstate)
+            acts.append(action.numpy()); logps.append(log_prob_res.numpy())
+            vals.append(value_state.numpy().reshape(())); rews.append(agent_reward.numpy().reshape(()))
+    out.update(actions=np.stack(acts), logps=np.stack(logps), values=np.stack(vals), rewards=np.stack(rews))
+    agent_all = pt.AgentBuffer.get()
+    expert_all = pt.ExpertBuffer.get()
+    for k, v in agent_all.items():
+        out["agent_get." + k] = v.numpy()
+    for k, v in expert_all.items():
+        out["expert_get." + k] = v.numpy()
+    np.random.seed(97)
+    for i, t in enumerate(pt.AgentBuffer.sampling(6)):
+        out["agent_sample.%d" % i] = t.numpy()
+    for i, t in enumerate(pt.ExpertBuffer.sampling(6)):
+        out["expert_sample.%d" % i] = t.numpy()
+    # ---- returns / advantages, :498-503 ----
+    returns = agent.calculate_returns(agent_all["rewards"], pt.DISCOUNT_FACTOR)
+    advantages = agent.calculate_advantages(returns, agent_all["values"])
+    out.update(returns=returns.numpy(), advantages=advantages.numpy(),
+               returns_raw=agent.calculate_returns(agent_all["rewards"], pt.DISCOUNT_FACTOR, normalize=False).numpy())
+    # ---- select_udpate, :293-346 ----
+    with torch.no_grad():
+        sa, sl, sv = agent.select_udpate(agent_all["states"])
+    out.update(select_action=sa.numpy(), select_logp=sl.numpy(), select_value=sv.numpy())
+    # ---- one inner step of update_policy, :365-417 (the optimizer steps are real; gradients stay in .grad) ----
+    mse_calls = []
+    real_mse = pt.F.mse_loss
+
+    def spy_mse(a, b, *args, **kw):
+        r = real_mse(a, b, *args, **kw)
+        mse_calls.append(float(r.detach().sum()))
+        return r
+
+    pt.F.mse_loss = spy_mse
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+            actor_loss = agent.update_policy(1, pt.PPO_CLIP, advantages, returns)
+    finally:
+        pt.F.mse_loss = real_mse
+    out.update(update_actor_loss=np.array(actor_loss, dtype=np.float64),
+               update_value_loss=np.array(mse_calls[0], dtype=np.float64))
+    pick = {"actor": ["in_linear.weight", "transformer_encoder.layers.0.attention.query_projection.weight",
+                      "transformer_encoder.layers.1.linear2.weight", "transformer_encoder.norm.weight",
+                      "proj_pitch.weight", "proj_tempo.bias", "word_emb_chord.lut.weight"],
+            "critic": ["in_linear.weight", "transformer_encoder.layers.1.attention.value_projection.weight",
+                       "proj_duration.weight", "pitch_value.weight", "velocity_value.bias"]}
+    for who, net in (("actor", agent.actor_net), ("critic", agent.critic_net)):
+        ps = dict(net.named_parameters())
+        for k in pick[who]:
+            g = ps[k].grad
+            out["grad.%s.%s" % (who, k)] = (g[:8] if g.numel() > 4096 else g).numpy()
+        out["gradnorm." + who] = np.array([ps[k].grad.double().norm().item() if ps[k].grad is not None else -1.0
+                                           for k in sorted(ps)])
+        out["gradnames." + who] = np.array(sorted(ps))
+    # ---- ring overwrite + seeded sampling with a buffer of 8 slots and 11 stores ----
+    pt.BUFFER_SIZE = 8
+    try:
+        ab, eb = pt.AgentMemory(), pt.ExpertMemory()
+        g2 = torch.Generator().manual_seed(1357)
+        stored = {k: [] for k in ("state", "action", "logp", "value", "reward", "next", "done", "mstate", "mnext")}
+        for i in range(11):
+            st, nx = _tokens(g2, (W,), n_token), _tokens(g2, (W,), n_token)
+            ac = _tokens(g2, (NA,), n_token)
+            lp = -3 * torch.rand(NA, 6, generator=g2)
+            va, rw = torch.randn(1, 1, generator=g2), torch.rand(1, 1, generator=g2)
+            dn = torch.tensor(i % 2).long()
+            ms, mn = (torch.rand(W, generator=g2) > 0.3).float(), (torch.rand(W, generator=g2) > 0.3).float()
+            ab.store_transition(st, ac, lp, va, rw, nx, dn)
+            eb.store_transition(st, ac, rw.reshape(()), nx, dn, ms, mn)
+            for k, v in zip(stored, (st, ac, lp, va, rw, nx, dn, ms, mn)):
+                stored[k].append(v.numpy())
+        for k, v in stored.items():
+            out["ring.in." + k] = np.stack(v)
+        for k, v in ab.get().items():
+            out["ring.agent_get." + k] = v.numpy()
+        for k, v in eb.get().items():
+            out["ring.expert_get." + k] = v.numpy()
+        out["ring.counter"] = np.array([ab.memory_counter, eb.memory_counter])
+        np.random.seed(4242)
+        for i, t in enumerate(ab.sampling(5)):
+            out["ring.agent_sample.%d" % i] = t.numpy()
+        for i, t in enumerate(eb.sampling(5)):
+            out["ring.expert_sample.%d" % i] = t.numpy()
+    finally:
+        pt.BUFFER_SIZE = pt.EPISODES
+    np.savez_compressed(os.path.join(HERE, "ppo_rl_small.npz"), **out)
+    big = {"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8}
+    config.ActorConfig.update(big)
+    config.CriticConfig.update(big)
+    config.DiscriConfig.update(big)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
+    if len(sys.argv) > 1:                      # python make_golden.py <fixture function> ...: only those
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
     dqn_small()
     dqn_repo_dims()
     ppo_small()
@@ -277,6 +440,7 @@ if __name__ == "__main__":
     airl_small()
     airl_grads_small()
     dqn_generation_small()
+    ppo_rl_small()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")

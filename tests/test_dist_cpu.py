@@ -17,6 +17,31 @@ def _model():
                                torch.nn.Linear(8, 1, bias=False))
 
 
+class _DirectLinear(torch.autograd.Function):
+    """y = x W^T + b whose backward writes dW, db straight into .grad (ops.deliver_grads) and returns None for them --
+    the pattern of the product's encoder layers.  Autograd still runs W's and b's AccumulateGrad with an undefined
+    gradient afterwards and fires their post-accumulate hooks: GradSync must take that as an echo, not a delivery."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        ctx.save_for_backward(x, w)
+        ctx.params = (w, b)
+        return x @ w.t() + b
+
+    @staticmethod
+    def backward(ctx, g):
+        from rlmg_amd import ops
+        x, w = ctx.saved_tensors
+        ops.deliver_grads(((ctx.params[0], g.t() @ x), (ctx.params[1], g.sum(0))))
+        return g @ w, None, None
+
+
+def _direct_forward(net, x):
+    lin1, act, lin2, lin3 = net
+    h = act(_DirectLinear.apply(x, lin1.weight, lin1.bias))
+    return lin3(_DirectLinear.apply(h, lin2.weight, lin2.bias))          # lin3 goes through autograd
+
+
 def _worker(rank, world, port, out):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
@@ -59,6 +84,13 @@ def _worker(rank, world, port, out):
     ops.deliver_grads(tuple(zip(ps[3:], gs[3:])))
     sync.finish()
     res["direct"] = [p.grad.clone() for p in net.parameters()]
+    # the same through autograd Functions that deliver directly (hook echoes; small buckets so that a bucket which
+    # launched after only part of its gradients -- counting an echo as a delivery -- gives a wrong result)
+    for step in range(2):
+        sync.zero_grad()
+        _direct_forward(net, xs).pow(2).mean().backward()
+        sync.finish()
+    res["direct_fn"] = [p.grad.clone() for p in net.parameters()]
     # A step that runs the network TWICE before one backward (DQN.update: TD pass + train_step; PPO's inner step:
     # select_udpate + train_step) delivers every directly-written gradient twice.  With the default overlap=True
     # sync that must fail loudly (a bucket would go on the wire after the first pass's gradients only) ...
@@ -109,7 +141,7 @@ def test_gradsync_world2_matches_single_process(tmp_path):
         assert torch.allclose(a, b, atol=0, rtol=0)
         assert torch.allclose(a, c, atol=1e-6)
     assert r0["double_raises"] is True and r1["double_raises"] is True
-    for key in ("accum", "direct", "double"):
+    for key in ("accum", "direct", "direct_fn", "double"):
         for a, b, c in zip(r0[key], r1[key], ref):
             assert torch.allclose(a, b, atol=0, rtol=0), key
             assert torch.allclose(a, c, atol=1e-6), key
