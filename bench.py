@@ -38,14 +38,18 @@ def synth_batch(B, T, seed, device):
     return x.to(device), y.to(device), mask.to(device)
 
 
+SCAN_BWD = "cwlt_causal_linear_bwd"              # the backward of one attention call, however many launches it takes
+SCAN_BWD_PARTS = ("cwlt_causal_linear_bwd", "cwlt_causal_linear_bwd_dkdv", "cwlt_causal_linear_bwd_dq")
+
+
 def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
-    """Algorithmic HBM bytes of ONE launch of a libcwlt entry point at this workload (DESIGN.md §Kernels).
-    s = bytes per activation element."""
+    """Algorithmic HBM bytes of ONE launch of a libcwlt entry point at this workload (DESIGN.md §Kernels; SURVEY §8d).
+    s = bytes per activation element.  The attention backward is priced as ONE unit whatever its launch count:
+    7 * D * s per token (Q, K, V, dOut read; dQ, dK, dV written) -- re-reads by a second kernel are waste, not work."""
     R = B * T
     return {
         "cwlt_causal_linear_fwd": R * (4 * D * s + H * 4),
-        "cwlt_causal_linear_bwd_dkdv": R * (6 * D * s + H * 4),
-        "cwlt_causal_linear_bwd_dq": R * (5 * D * s + H * 4),
+        SCAN_BWD: R * (7 * D * s + H * 4),
         "cwlt_add_dropout_layernorm_fwd": R * (4 * D * s + 8),
         "cwlt_add_dropout_layernorm_bwd": R * (5 * D * s + 8),
         "cwlt_bias_gelu_dropout_fwd": R * 2 * F * s,
@@ -59,12 +63,12 @@ def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
     }.get(entry)
 
 
-def algorithmic_flops(entry, B, T, D=512, F=2048):
-    """MFMA-bound entry points: FLOPs of ONE launch (mean over the shapes it is called with per layer)."""
+def wgrad_flops_per_step(B, T, D=512, F=2048, ncat=1216, W=384):
+    """FLOPs of all weight-gradient GEMMs of one step, shape by shape: per layer dW2 (D x F), dW1 (F x D), dWo (D x D),
+    dWqkv (3D x D); once in_linear (D x 1216) and the fused head projection (384 x D).  (Cross-check of the per-call
+    figures the launches themselves declare through ops._call(work=...).)"""
     R = B * T
-    if entry == "cwlt_wgrad_bf16":     # dW2 (D x F), dW1 (F x D), dWo (D x D), dWqkv (3D x D)
-        return 2.0 * R * (2 * D * F + D * D + 3 * D * D) / 4
-    return None
+    return 2.0 * R * (12 * (2 * D * F + D * D + 3 * D * D) + D * ncat + W * D)
 
 
 def usable_cores():
@@ -116,6 +120,109 @@ def cpu_baseline(seconds_budget=30.0):
             "sample": "%d steps of B=1 x T=1024 (fwd+bwd+clip+Adam, fp32, dropout 0.1), oracle/cw_model.py" % n}
 
 
+def roofline_entry(name, kind, achieved, avg_ms, share, work_per_launch, traffic=None):
+    peak = HBM_PEAK_GBS if kind == "hbm" else MFMA_BF16_PEAK / 1e12
+    return {"kernel": name, "bound": kind, "achieved": round(achieved, 1), "peak": peak,
+            "unit": "GB/s" if kind == "hbm" else "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
+            ("algorithmic_bytes_per_launch" if kind == "hbm" else "flop_per_launch"): work_per_launch,
+            "avg_launch_ms": round(avg_ms, 4), "share_of_step": round(share, 4)}
+
+
+def kernel_table(kt, B, T, s, ms_per_step, n_sampled):
+    """-> (kernels dict for the JSON line, list of roofline candidates (total ms per step, entry))."""
+    kernels, cands = {}, []
+    merged = dict(kt)
+    parts = [k for k in SCAN_BWD_PARTS if k in kt]
+    if parts:                                   # the attention backward as ONE unit: launches per call summed
+        calls = max(kt[k][0] for k in parts)
+        merged[SCAN_BWD] = (calls, sum(kt[k][0] * kt[k][1] for k in parts) / calls, None)
+    for k, (c, m, work) in sorted(merged.items(), key=lambda kv: -kv[1][0] * kv[1][1]):
+        own = k in kt
+        if k in SCAN_BWD_PARTS and k != SCAN_BWD:
+            kernels[k] = {"calls_per_step": c / n_sampled, "avg_ms": round(m, 4), "part_of": SCAN_BWD}
+            continue
+        ab = algorithmic_bytes(k, B, T, s=s)
+        e = {"calls_per_step": c / n_sampled, "avg_ms": round(m, 4),
+             "share_of_step": round(c * m / n_sampled / ms_per_step, 4)}
+        if ab:
+            e["GB/s"] = round(ab / (m * 1e-3) / 1e9, 1)
+            cands.append((c * m / n_sampled, roofline_entry(k, "hbm", ab / (m * 1e-3) / 1e9, m,
+                                                            c * m / n_sampled / ms_per_step, ab)))
+        if work:
+            e["TFLOP/s"] = round(work / (m * 1e-3) / 1e12, 1)
+            cands.append((c * m / n_sampled, roofline_entry(k, "mfma", work / (m * 1e-3) / 1e12, m,
+                                                            c * m / n_sampled / ms_per_step, work)))
+        if not own:
+            e["launches"] = parts
+        kernels[k] = e
+    return kernels, cands
+
+
+def report(args, kt, B, T, s, world, ms_per_step, tokens_per_s, final_loss, replica_spread, tuned, hbm_peak):
+    roofline = roofline_hbm = roofline_mfma = None
+    kernels = {}
+    if kt:
+        n_sampled = len([i for i in range(args.steps) if i % 10 == 0])     # steps on which events were recorded
+        kernels, cands = kernel_table(kt, B, T, s, ms_per_step, n_sampled)
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        traffic = {}
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if tj.get("batch") == B and tj.get("seq") == T and tj.get("dtype") == args.dtype:
+                traffic = tj.get("per_launch_bytes", {})
+        for _, e in cands:
+            e["traffic"] = traffic.get(e["kernel"])
+        cands.sort(key=lambda t: -t[0])
+        # `roofline`: the libcwlt entry point with the largest total time in the step, whatever bounds it;
+        # `roofline_hbm` / `roofline_mfma`: the largest one of each kind
+        roofline = cands[0][1]
+        roofline_hbm = next((e for _, e in cands if e["bound"] == "hbm"), None)
+        roofline_mfma = next((e for _, e in cands if e["bound"] == "mfma"), None)
+        if "cwlt_wgrad_bf16" in kt:                 # cross-check: declared per-call FLOPs vs the shape table
+            c, m, work = kt["cwlt_wgrad_bf16"]
+            kernels["cwlt_wgrad_bf16"]["flop_per_step_declared"] = work * c / n_sampled
+            kernels["cwlt_wgrad_bf16"]["flop_per_step_shapes"] = wgrad_flops_per_step(B, T)
+    return {
+        "metric": "CW-tokens/sec pretrain fwd+bwd @T=1024", "value": round(tokens_per_s, 1), "unit": "CW-tokens/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "agent_pretrain step (fwd+bwd+clip+Adam), repo dims 512/12/8/2048, "
+                               "synthetic CW tokens (B=%d/GPU, T=%d, 7 fields -> 6)" % (B, T),
+                   "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
+                   "parallelism": "dp%d" % world, "dropout": 0.1, "params": 38982227,
+                   "gemm_table": str(tuned)},
+        "final_loss": final_loss, "replica_spread": replica_spread, "hbm_peak_gb": hbm_peak,
+        "model_mfma_frac": round(tokens_per_s / world * FLOP_PER_TOKEN / MFMA_BF16_PEAK, 4),
+        "roofline": roofline, "roofline_hbm": roofline_hbm, "roofline_mfma": roofline_mfma, "kernels": kernels,
+    }
+
+
+def ppo_report(args, ppo, world):
+    """BASELINE.json metric, second half: PPO env-steps/s on configs[2] (64 rollouts x window 1024 per GPU)."""
+    R, W = args.ppo_rollouts, args.ppo_window
+    kt = ppo["kernel_times"]
+    dom = None
+    if kt:
+        tot = {k: c * m for k, (c, m, _) in kt.items()}
+        k = max(tot, key=tot.get)
+        c, m, work = kt[k]
+        dom = {"kernel": k, "calls_per_iteration": c, "avg_ms": round(m, 4),
+               "share_of_iteration": round(tot[k] / ppo["ms_per_iteration"], 4)}
+        if work:
+            dom.update({"bound": "mfma", "TFLOP/s": round(work / (m * 1e-3) / 1e12, 1),
+                        "frac": round(work / (m * 1e-3) / MFMA_BF16_PEAK, 4)})
+    return {"metric": "PPO env-steps/sec", "value": round(ppo["env_steps_per_s"], 2), "unit": "env-steps/s",
+            "rollout_only_env_steps_per_s": round(ppo["rollout_only_env_steps_per_s"], 2),
+            "ms_per_iteration": round(ppo["ms_per_iteration"], 1), "n_gpus": world, "scaling": "weak",
+            "replica_spread": ppo["replica_spread"], "dominant_kernel": dom,
+            "config": {"workload": "ppo_train iteration (ppo_policy/ppo_train.py:460-506): %d rollouts/GPU x window %d, "
+                                   "EPISODES 30, PPO_STEPS %d, actor/critic 512/12/8, reward Longformer 512/12/8 w=512; "
+                                   "env-step = actor greedy fwd + critic value + reward model + buffer write; "
+                                   "1 warm-up + 1 timed iteration" % (R, W, args.ppo_steps),
+                       "rollouts_per_gpu": R, "window": W, "episodes": 30, "ppo_steps": args.ppo_steps,
+                       "update_group": 8, "hipgraph_rollout": ppo["hipgraph_rollout"]}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,6 +235,10 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--tune-gemms", action="store_true", help="re-tune the hipBLASLt/rocBLAS table (GPU box)")
     ap.add_argument("--no-tuned-gemms", action="store_true")
+    ap.add_argument("--no-ppo", action="store_true", help="skip the PPO env-steps/s block (BASELINE's second metric)")
+    ap.add_argument("--ppo-rollouts", type=int, default=64)
+    ap.add_argument("--ppo-window", type=int, default=1024)
+    ap.add_argument("--ppo-steps", type=int, default=10)
     args = ap.parse_args()
 
     import rlmg_amd  # noqa: F401
@@ -210,6 +321,10 @@ def main():
     ms_per_step = 1e3 * dt / args.steps
     tokens_per_s = world * B * T * args.steps / dt
     replica_spread = None
+    kt_pretrain = ops.KernelTimer.summary() if rank == 0 else {}
+    ops.KernelTimer.reset(False)
+    final_loss = round(float(loss.item()), 4)
+    hbm_peak = round(torch.cuda.max_memory_allocated() / 1e9, 1)
     if world > 1:
         # data-parallel sanity (outside the timed region): every rank must hold the same parameters after the
         # all-reduced steps; spread = max over ranks - min over ranks of a parameter checksum
@@ -220,61 +335,35 @@ def main():
         replica_spread = float((hi - lo).item())
         log("replica parameter checksum spread: %.3e" % replica_spread)
 
+    ppo = None
+    if not args.no_ppo:
+        # BASELINE.json's second metric (PPO env-steps/s, configs[2]: 64 rollouts x window 1024 per GPU), measured in
+        # the same driver-run process after the pretrain region; the pretrain model and its optimizer are released first
+        del net, opt, sync, x, y, mask, loss
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+        import bench_ppo
+        log("ppo block: %d rollouts x window %d, EPISODES %d, PPO_STEPS %d" % (args.ppo_rollouts, args.ppo_window, 30,
+                                                                              args.ppo_steps))
+        ppo = bench_ppo.run(args.ppo_rollouts, args.ppo_window, 30, args.ppo_steps, iters=1, warmup=1, dtype=args.dtype,
+                            group=8, rank=rank, world=world, dev=dev, timer=True)
+
     if rank == 0:
         s = 2 if args.dtype == "bf16" else 4
-        kt = ops.KernelTimer.summary()
-        roofline = None
-        kernels = {}
-        if kt:
-            n_sampled = len([i for i in range(args.steps) if i % 10 == 0])     # steps on which events were recorded
-            tot = {k: c * m for k, (c, m) in kt.items()}
-            for k, (c, m) in sorted(kt.items(), key=lambda kv: -tot[kv[0]]):
-                ab = algorithmic_bytes(k, B, T, s=s)
-                fl = algorithmic_flops(k, B, T)
-                kernels[k] = {"calls_per_step": c / n_sampled, "avg_ms": round(m, 4),
-                              "share_of_step": round(tot[k] / n_sampled / ms_per_step, 4),
-                              "GB/s": round(ab / (m * 1e-3) / 1e9, 1) if ab else None}
-                if fl:
-                    kernels[k]["TFLOP/s"] = round(fl / (m * 1e-3) / 1e12, 1)
-            # roofline: the HBM-bound libcwlt entry point with the largest total time (the MFMA-bound
-            # weight-gradient GEMM is reported alongside in `kernels` and `roofline_mfma`)
-            hbm = {k: v for k, v in tot.items() if algorithmic_bytes(k, B, T, s=s)}
-            dom = max(hbm, key=hbm.get)
-            ab = algorithmic_bytes(dom, B, T, s=s)
-            ach = ab / (kt[dom][1] * 1e-3) / 1e9
-            traffic = None
-            tpath = os.path.join(ROOT, "profiles", "traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if tj.get("batch") == B and tj.get("seq") == T and tj.get("dtype") == args.dtype:
-                    traffic = tj.get("per_launch_bytes", {}).get(dom)
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "algorithmic_bytes_per_launch": ab, "avg_launch_ms": round(kt[dom][1], 4)}
-        out = {
-            "metric": "CW-tokens/sec pretrain fwd+bwd @T=1024", "value": round(tokens_per_s, 1), "unit": "CW-tokens/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "agent_pretrain step (fwd+bwd+clip+Adam), repo dims 512/12/8/2048, "
-                                   "synthetic CW tokens (B=%d/GPU, T=%d, 7 fields -> 6)" % (B, T),
-                       "per_gpu_batch": B, "global_batch": B * world, "seq_len": T,
-                       "parallelism": "dp%d" % world, "dropout": 0.1, "params": 38982227,
-                       "gemm_table": str(tuned)},
-            "final_loss": round(float(loss.item()), 4), "replica_spread": replica_spread,
-            "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
-            "model_mfma_frac": round(tokens_per_s / world * FLOP_PER_TOKEN / MFMA_BF16_PEAK, 4),
-            "roofline": roofline, "kernels": kernels,
-        }
-        if "cwlt_wgrad_bf16" in kt:
-            fl = algorithmic_flops("cwlt_wgrad_bf16", B, T)
-            ach_tf = fl / (kt["cwlt_wgrad_bf16"][1] * 1e-3) / 1e12
-            out["roofline_mfma"] = {"kernel": "cwlt_wgrad_bf16", "bound": "mfma", "achieved": round(ach_tf, 1),
-                                    "peak": MFMA_BF16_PEAK / 1e12, "unit": "TFLOP/s",
-                                    "frac": round(ach_tf * 1e12 / MFMA_BF16_PEAK, 4), "traffic": None}
+        kt = kt_pretrain
+        out = report(args, kt, B, T, s, world, ms_per_step, tokens_per_s, final_loss, replica_spread, tuned, hbm_peak)
+        if ppo is not None:
+            out["ppo"] = ppo_report(args, ppo, world)
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline()
             out["cpu_baseline"] = cb
             out["gpu_over_cpu"] = round(tokens_per_s / cb["value"], 1)
+            if ppo is not None:
+                import bench_ppo
+                pc = bench_ppo.cpu_rollout_baseline(args.ppo_window)
+                out["ppo"]["cpu_baseline"] = pc
+                out["ppo"]["gpu_over_cpu_rollout_only"] = round(out["ppo"]["rollout_only_env_steps_per_s"] / pc["value"], 1)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -35,39 +35,18 @@ def log(msg):
     print("[bench_ppo] " + msg, file=sys.stderr, flush=True)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--rollouts", type=int, default=64, help="parallel rollouts per GPU")
-    ap.add_argument("--window", type=int, default=1024)
-    ap.add_argument("--episodes", type=int, default=30)
-    ap.add_argument("--ppo-steps", type=int, default=10)
-    ap.add_argument("--iters", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--group", type=int, default=8, help="rollouts stacked per update pass (1 = one at a time)")
-    ap.add_argument("--tune-gemms", action="store_true", help="extend the GEMM table with this workload's shapes")
-    ap.add_argument("--no-graphs", action="store_true", help="launch the rollout step eagerly (no hipGraph)")
-    args = ap.parse_args()
-
+def run(rollouts=64, window=1024, episodes=30, ppo_steps=10, iters=1, warmup=1, dtype="bf16", group=8,
+        rank=0, world=1, dev=None, timer=False):
+    """One PPO + IRL workload (see the module docstring) on an ALREADY initialised process group / device.
+    -> dict(env_steps_per_s, rollout_only_env_steps_per_s, ms_per_iteration, replica_spread, kernel_times)
+    `timer`: one extra, untimed iteration with every libcwlt call bracketed by HIP events (rank 0)."""
     import rlmg_amd  # noqa: F401
-    from rlmg_amd import dist as rdist, gemm_tuning, ops, rl_ops
+    from rlmg_amd import ops, rl_ops
     from rlmg_amd.ppo_policy import config as pcfg, ppo_train as P
 
-    if args.no_graphs:
-        ops.GRAPHS_ENABLED = False
-    rank, local, world = rdist.init_from_env()
-    if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if args.tune_gemms:
-        gemm_tuning.tune(os.path.join(ROOT, "gpurun_out", "gemm_gfx950.csv"))
-    else:
-        gemm_tuning.enable()
-    R, W, E = args.rollouts, args.window, args.episodes
+    R, W, E = rollouts, window, episodes
     NA = W // 2
-    G = max(1, args.group)
+    G = max(1, group)
     P.N_ACTIONS = P.NUM_ACTION = NA
     P.N_STATES = P.WINDOW_SIZE = W
     n_token = [49, 19, 19, 89, 67, 25]
@@ -79,7 +58,7 @@ def main():
     torch.manual_seed(0)
     with contextlib.redirect_stdout(io.StringIO()):
         agent = P.PPO(n_token, Pretrain=False)
-    adt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    adt = torch.bfloat16 if dtype == "bf16" else torch.float32
     for net in (agent.actor_net, agent.critic_net, agent.eval_net):
         net.compute_dtype = adt
     g = torch.Generator().manual_seed(1234 + rank)
@@ -109,7 +88,7 @@ def main():
             ret, adv = rl_ops.ppo_returns_adv(rewards[:, r], values[:, r], P.DISCOUNT_FACTOR, True)
             rets.append(ret)
             advs.append(adv)
-        for _ in range(args.ppo_steps):
+        for _ in range(ppo_steps):
             agent.update_rollouts(states, old_int, advs, rets, expert, mask, group=G)
         return t_roll
 
@@ -118,17 +97,31 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
+    for i in range(warmup):
         iteration()
         log("warm-up iteration %d done" % i)
     fence()
+    ops.KernelTimer.reset(False)
     t0 = time.perf_counter()
     t_roll = 0.0
-    for i in range(args.iters):
+    for i in range(iters):
         t_roll += iteration()
         log("iteration %d done" % i)
     fence()
     dt = time.perf_counter() - t0
+    kernel_times = {}
+    if timer:
+        # one EXTRA iteration, outside the timed region, with a pair of HIP events around every libcwlt call (the
+        # events make the GPU drain between kernels, so they must not sit inside the measured iterations)
+        if rank == 0:
+            ops.KernelTimer.reserve(8192)
+            torch.cuda.synchronize()
+            ops.KernelTimer.enabled = True
+        iteration()
+        fence()
+        ops.KernelTimer.enabled = False
+        kernel_times = ops.KernelTimer.summary() if rank == 0 else {}
+        ops.KernelTimer.reset(False)
     replica_spread = None
     if world > 1:
         t = torch.tensor([dt, t_roll], device=dev, dtype=torch.float64)
@@ -142,17 +135,105 @@ def main():
         torch.distributed.all_reduce(lo, op=torch.distributed.ReduceOp.MIN)
         replica_spread = float((hi - lo).item())
         log("replica parameter checksum spread: %.3e" % replica_spread)
+    steps = world * R * E * iters
+    return {"env_steps_per_s": steps / dt, "rollout_only_env_steps_per_s": steps / t_roll,
+            "ms_per_iteration": 1e3 * dt / iters, "replica_spread": replica_spread, "kernel_times": kernel_times,
+            "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "tokens_per_update_pass": E * W * min(G, R)}
+
+
+def cpu_rollout_baseline(window=1024, seconds_budget=20.0):
+    """One environment step of the reference's rollout loop (ppo_train.py:475-496: actor greedy action + log-probs,
+    next state, critic value, reward model) through the CPU oracle, fp32, all usable host cores -> env-steps/s."""
+    import bench as _b
+    from oracle import cw_model, discriminator as odisc, rl_math
+    import rlmg_amd  # noqa: F401
+    from rlmg_amd.ppo_policy import config as pcfg, model as pmodel
+    cores = _b.usable_cores()
+    torch.set_num_threads(cores)
+    n_token = [49, 19, 19, 89, 67, 25]
+    torch.manual_seed(0)
+    actor = cw_model.CWLinearTransformer(n_token, 512, 12, 8, variant="actor").eval()
+    critic = cw_model.CWLinearTransformer(n_token, 512, 12, 8, variant="critic").eval()
+    old = dict(pcfg.DiscriConfig)
+    pcfg.DiscriConfig["MAX_SEQ"] = max(old["MAX_SEQ"], window + 2)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()):
+            reward = pmodel.LongFormer(n_token)               # CPU parameter container for the oracle's state dict
+    finally:
+        pcfg.DiscriConfig.update(old)
+    sd = {k: v.detach() for k, v in reward.state_dict().items()}
+    g = torch.Generator().manual_seed(1)
+    state = torch.stack([torch.randint(0, n, (1, window), generator=g) for n in n_token], -1)
+    m = torch.ones(1, window, dtype=torch.long)
+
+    def step(state):
+        with torch.no_grad():
+            ys = actor.forward_output(actor.forward_hidden(state))
+            action, _ = rl_math.ppo_choose_action(ys, window // 2)
+            nxt = torch.cat((state[0, :window // 2], action), 0).unsqueeze(0)
+            critic.value_produce(nxt)
+            odisc.ppo_reward_forward(sd, nxt, m, 12, 8, 512)
+        return nxt
+
+    step(state)                                               # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 1 or (time.perf_counter() - t0 < seconds_budget * 0.5 and n < 8):
+        state = step(state)
+        n += 1
+    dt = (time.perf_counter() - t0) / n
+    return {"value": round(1.0 / dt, 3), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": "%d rollout steps of ONE rollout x window %d (actor + critic + reward model forward, fp32), "
+                      "oracle/{cw_model,rl_math,discriminator}.py" % (n, window)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--rollouts", type=int, default=64, help="parallel rollouts per GPU")
+    ap.add_argument("--window", type=int, default=1024)
+    ap.add_argument("--episodes", type=int, default=30)
+    ap.add_argument("--ppo-steps", type=int, default=10)
+    ap.add_argument("--iters", type=int, default=1)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--group", type=int, default=8, help="rollouts stacked per update pass (1 = one at a time)")
+    ap.add_argument("--tune-gemms", action="store_true", help="extend the GEMM table with this workload's shapes")
+    ap.add_argument("--no-graphs", action="store_true", help="launch the rollout step eagerly (no hipGraph)")
+    ap.add_argument("--cpu-baseline", action="store_true", help="also time one oracle rollout step on the host cores")
+    args = ap.parse_args()
+
+    import rlmg_amd  # noqa: F401
+    from rlmg_amd import dist as rdist, gemm_tuning, ops
+
+    if args.no_graphs:
+        ops.GRAPHS_ENABLED = False
+    rank, local, world = rdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if args.tune_gemms:
+        gemm_tuning.tune(os.path.join(ROOT, "gpurun_out", "gemm_gfx950.csv"))
+    else:
+        gemm_tuning.enable()
+    R, W, E = args.rollouts, args.window, args.episodes
+    res = run(R, W, E, args.ppo_steps, args.iters, args.warmup, args.dtype, args.group, rank, world, dev)
     if rank == 0:
-        steps = world * R * E * args.iters
-        print(json.dumps({
-            "metric": "PPO env-steps/sec", "value": round(steps / dt, 2), "unit": "env-steps/s", "n_gpus": world,
-            "steps": args.iters, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.iters, 1),
+        out = {
+            "metric": "PPO env-steps/sec", "value": round(res["env_steps_per_s"], 2), "unit": "env-steps/s",
+            "n_gpus": world, "steps": args.iters, "warmup": args.warmup, "ms_per_step": round(res["ms_per_iteration"], 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "rollout_only_env_steps_per_s": round(steps / t_roll, 2), "replica_spread": replica_spread,
+            "rollout_only_env_steps_per_s": round(res["rollout_only_env_steps_per_s"], 2),
+            "replica_spread": res["replica_spread"],
             "config": {"workload": "ppo_train iteration: %d rollouts/GPU x window %d, EPISODES %d, PPO_STEPS %d, "
                                    "actor/critic 512/12/8, reward Longformer 512/12/8 w=512" % (R, W, E, args.ppo_steps),
-                       "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "update_group": G, "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
-                       "parallelism": "dp%d" % world}}), flush=True)
+                       "hipgraph_rollout": res["hipgraph_rollout"], "update_group": max(1, args.group),
+                       "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
+                       "parallelism": "dp%d" % world}}
+        if args.cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_rollout_baseline(W)
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()

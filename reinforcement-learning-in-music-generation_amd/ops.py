@@ -76,14 +76,17 @@ class KernelTimer:
 
     @classmethod
     def summary(cls):
+        """{entry point: (calls, mean ms, mean work per call or None)} -- `work` is what the caller declared for
+        the launch (FLOPs of a weight-gradient GEMM of that very shape), so rates use the real per-call shapes."""
         out = {}
         for name, evs in cls.records.items():
-            ms = [a.elapsed_time(b) for a, b in evs]
-            out[name] = (len(ms), sum(ms) / max(1, len(ms)))
+            ms = [a.elapsed_time(b) for a, b, _ in evs]
+            works = [w for _, _, w in evs if w is not None]
+            out[name] = (len(ms), sum(ms) / max(1, len(ms)), (sum(works) / len(works)) if works else None)
         return out
 
 
-def _call(name, *args):
+def _call(name, *args, work=None):
     """Invoke one libcwlt entry point on the current stream and raise on a non-zero status."""
     fn = getattr(_lib.load(), name)
     if KernelTimer.enabled:
@@ -91,7 +94,7 @@ def _call(name, *args):
         a.record()
         st = fn(*args)
         b.record()
-        KernelTimer.records.setdefault(name, []).append((a, b))
+        KernelTimer.records.setdefault(name, []).append((a, b, work))
     else:
         st = fn(*args)
     _lib.check(st, name)
@@ -542,7 +545,7 @@ def wgrad(a, b, out=None, accumulate=False):
         out = torch.empty((N1, N2), dtype=torch.float32, device=a.device)
         accumulate = False
     _call("cwlt_wgrad_bf16", _lib.dev(a, "a"), _lib.dev(b, "b"), _lib.dev(part), _lib.dev(out), M, N1, N2,
-          a.stride(0), b.stride(0), 1 if accumulate else 0, _lib.stream_ptr())
+          a.stride(0), b.stride(0), 1 if accumulate else 0, _lib.stream_ptr(), work=2.0 * M * N1 * N2)
     return out
 
 

@@ -14,6 +14,7 @@ _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import ops  # noqa: E402
 from rlmg_amd.cw_transformer import ATTRS, CWTrunk, Embeddings, PositionalEncoding  # noqa: E402,F401
 from rlmg_amd.discriminator import CWLongformerBase  # noqa: E402
 from rlmg_amd.sampling import nucleus, sample_cw, sampling, softmax_with_temperature, weighted_sampling  # noqa: E402,F401
@@ -76,9 +77,13 @@ class Critic_Transformer(CWTrunk):
         return total / len(self.n_token)
 
 
+LinearTransformer = Actor_Transformer     # the name ppo_policy/my_pretrain.py:18 imports (its model.py never defines it)
+
+
 class LongFormer(CWLongformerBase):
-    """ppo_policy/model.py:400-495: the frozen reward model.  12-layer Longformer with attention_window =
-    D_MODEL (512); the reference pads the 50-token window to 512 -- here the band simply covers the window."""
+    """ppo_policy/model.py:400-495: the reward model (frozen inside ppo_train.py, trained by
+    `my_pretrain.py --reward_pretrain`).  12-layer Longformer with attention_window = D_MODEL (512); the reference
+    pads the 50-token window to 512 -- here the band simply covers the window."""
 
     def __init__(self, n_token):
         super().__init__(n_token, DiscriConfig["D_MODEL"], DiscriConfig["N_LAYER"], DiscriConfig["N_HEAD"],
@@ -91,14 +96,27 @@ class LongFormer(CWLongformerBase):
 
     def token_forward(self, data, target, loss_mask):
         """(B, T, 6), _, (B, T) -> (B, 1): mean over the 6 attributes of sigmoid(mean_T eval_f(proj_f(h))).
-        `target` is unused, as in the reference (:459)."""
-        with torch.no_grad():
-            h = self._encode(data, loss_mask)
-            B, T = h.shape[0], h.shape[1]
-            logits = self._fused_logits(h).float().view(B, T, -1).mean(dim=1)
-            total, o = 0, 0
-            for name, n in zip(ATTRS, self.n_token):
-                head = getattr(self, "eval_" + name)
-                total = total + torch.sigmoid(torch.nn.functional.linear(logits[:, o:o + n], head.weight, head.bias))
-                o += n
-            return total / len(self.n_token)
+        `target` is unused, as in the reference (:459).  Differentiable, as in the reference, when autograd is on
+        (the RL loop calls it under torch.no_grad(): ppo_train.py::_rollout_step_device)."""
+        h = self._encode(data, loss_mask)
+        B, T = h.shape[0], h.shape[1]
+        logits = self._fused_logits(h).float().view(B, T, -1).mean(dim=1)
+        total, o = 0, 0
+        for name, n in zip(ATTRS, self.n_token):
+            head = getattr(self, "eval_" + name)
+            total = total + torch.sigmoid(torch.nn.functional.linear(logits[:, o:o + n], head.weight, head.bias))
+            o += n
+        return total / len(self.n_token)
+
+    def train_step(self, x, target, loss_mask):
+        """What `my_pretrain.py --reward_pretrain` calls on this class (my_pretrain.py:78,184).  The reference's
+        LongFormer never defines it (that branch raises AttributeError as committed); the losses it has the pieces
+        for are the six per-attribute `compute_CEloss(proj_f(h), target_f, mask)` -- the same token CE its DQN-side
+        twin computes (dqn_policy/AIRL_model.py:131-170) -- so that is what this returns: 6 losses, each
+        (mean CE * mask).sum() / mask.sum() = the plain mean CE over all positions (compute_CEloss's arithmetic)."""
+        h = self._encode(x, loss_mask)
+        logits = self._fused_logits(h)
+        rows = logits.shape[0]
+        ones = torch.ones(rows, device=logits.device)
+        losses = ops.heads_ce(logits, target.reshape(rows, len(self.n_token)), ones, self.n_token)
+        return tuple(losses[i] for i in range(len(self.n_token)))

@@ -1,0 +1,140 @@
+"""Drop-in for /root/reference/ppo_policy/my_pretrain.py: the PPO-side pretraining loop -- `pretrain()` and `main()`
+with `--reward_pretrain` -- on the libcwlt kernels.
+
+    python my_pretrain.py                    agent pretraining (Actor_Transformer; the reference imports it under
+                                             the name `LinearTransformer`, which its model.py never defines)
+    python my_pretrain.py --reward_pretrain  reward-model pretraining (LongFormer.train_step: see ppo_policy/model.py)
+
+Same recipe as the reference (my_pretrain.py:34-135, 184-198): batches of 12 in dataset order, loss = mean of the six
+CE losses, Adam(lr 1e-2), MultiStepLR(milestones [500, NUM_EPOCH], gamma 0.1) stepped once per BATCH,
+`pretrain_best.pth` (bare state_dict) every 10 epochs, `config_log.txt`, the per-batch `\\r` progress line.
+wandb logging and the loss plot are not reproduced (SURVEY: out of scope).  Data parallel (new): rank-strided
+batches, gradients reduced once per step.  Environment knobs for short runs: CWLT_N_EPOCH.
+"""
+import argparse
+import os
+import pickle
+import sys
+import time
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if _ROOT not in sys.path:
+    sys.path.insert(0, _ROOT)
+import rlmg_amd  # noqa: E402,F401
+from rlmg_amd import data as cwdata, dist as rdist  # noqa: E402
+
+try:
+    from model import LinearTransformer, LongFormer, network_paras
+    from config import datapath, device, MaxSeqLen  # noqa: F401
+except ImportError:
+    from .model import LinearTransformer, LongFormer, network_paras
+    from .config import datapath, device, MaxSeqLen  # noqa: F401
+
+train_datapath = "./dataset/our_dataset.pickle"
+
+BATCH_SIZE = 12
+NUM_EPOCH = int(os.environ.get("CWLT_N_EPOCH", 1000))
+Init_lr = 0.01
+
+
+def write_config_log(logfile_path, purpose, len_train_x, len_train_y, epochs, batch_size, lr):
+    """utils_file.py:21-28 takes six parameters but my_pretrain.py:54 passes seven (a TypeError as committed); the
+    file written here has the reference's five lines with both shapes on the second."""
+    with open(logfile_path, "w") as f:
+        f.write(f"Model Type      = {purpose}\n")
+        f.write(f"Model Type      = {tuple(len_train_x)} {tuple(len_train_y)}\n")
+        f.write(f"Num epochs      = {epochs}\n")
+        f.write(f"Batch size      = {batch_size}\n")
+        f.write(f"Learning rate   = {lr}\n")
+
+
+def pretrain(model, my_dataset, optimizer, scheduler, flag, config_path, ckpt_path, num_epoch=None, sync=None,
+             log=print):
+    """my_pretrain.py:34-135.  -> list of the last batch's loss per epoch (the reference's `record_loss`)."""
+    num_epoch = NUM_EPOCH if num_epoch is None else num_epoch
+    rank = torch.distributed.get_rank() if (sync is not None and sync.world > 1) else 0
+    world = sync.world if sync is not None else 1
+    train_x, train_y, mask = my_dataset["train_x"], my_dataset["train_y"], my_dataset["mask"]
+    num_batch = len(train_x) // (BATCH_SIZE * world)
+    log("    num_batch:", num_batch)
+    log("    train_x:", train_x.shape)
+    log("    train_y:", train_y.shape)
+    log("    train_mask:", mask.shape)
+    purpose = "Pretrain with Longformer for reward model" if flag else "Pretrain with Linearformer for agent."
+    if rank == 0:
+        write_config_log(config_path, purpose, train_x.shape, train_y.shape, num_epoch, BATCH_SIZE, Init_lr)
+    if sync is None:
+        sync = rdist.GradSync(model.parameters(), overlap=True)
+    record_loss = []
+    start_time = time.time()
+    for epoch in range(num_epoch):
+        acc_loss, arr_losses = 0.0, np.zeros(6)
+        CELoss = None
+        for bidx in range(num_batch):
+            st = BATCH_SIZE * (bidx * world + rank)
+            batch_x = torch.from_numpy(train_x[st:st + BATCH_SIZE]).long().to(device)
+            batch_y = torch.from_numpy(train_y[st:st + BATCH_SIZE]).long().to(device)
+            batch_mask = torch.from_numpy(mask[st:st + BATCH_SIZE]).float().to(device)
+            losses = model.train_step(batch_x, batch_y, batch_mask)
+            CELoss = (losses[0] + losses[1] + losses[2] + losses[3] + losses[4] + losses[5]) / 6
+            sync.zero_grad()
+            CELoss.backward()
+            sync.finish()
+            optimizer.step()
+            scheduler.step()                               # per batch, as in the reference (:89)
+            vals = [l.item() for l in losses]
+            arr_losses += np.array(vals)
+            acc_loss += CELoss.item()
+            sys.stdout.write("Epoch: {}/{} | Batch:{}/{} | Loss: {:06f} | {:04f}, {:04f}, {:04f}, {:04f}, {:04f}, {:04f}\r"
+                             .format(epoch, num_epoch, bidx, num_batch, CELoss.item(), *vals))
+            sys.stdout.flush()
+        if CELoss is not None:
+            record_loss.append(CELoss.item())
+        if epoch % 10 == 0 and rank == 0:
+            torch.save(model.state_dict(), os.path.join(ckpt_path, "pretrain_best.pth"))
+    with open(os.path.join(ckpt_path, "pretrain_loss.pickle"), "wb") as f:      # in place of the reference's loss plot
+        pickle.dump({"record_loss": record_loss, "seconds": time.time() - start_time}, f)
+    return record_loss
+
+
+def main(argv=None):
+    parser = argparse.ArgumentParser()
+    parser.add_argument("--reward_pretrain", help="Reward Model Pretrain", action="store_true", default=False)
+    args = parser.parse_args(argv)
+    rank, local, world = rdist.init_from_env()
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local)
+    exp_name = datetime.now().strftime("%Y_%m_%d_%H_%M_%S")
+    exp_dir = os.path.join("./Exp-Pretrain", exp_name)
+    model_save_path = os.path.join(exp_dir, "model")
+    log_dir = os.path.join(exp_dir, "log")
+    os.makedirs(model_save_path, exist_ok=True)
+    os.makedirs(log_dir, exist_ok=True)
+    config_path = os.path.join(log_dir, "config_log.txt")
+
+    dictionary, my_dataset = cwdata.load_ppo(datapath["path_dictionary"], train_datapath)
+    event2word, word2event = dictionary
+    num_token = [len(event2word[etype]) + 1 for etype in event2word.keys()]        # +1: pad word (:176-178)
+    print("Num of token class >>", num_token)
+    if args.reward_pretrain:
+        model = LongFormer(num_token).to(device)
+        print("Reward Model Pretraining...")
+    else:
+        model = LinearTransformer(num_token, is_training=True).to(device)
+        print("Agent Pretraining...")
+    model.train()
+    print("Model_parameters: {:,}".format(network_paras(model)))
+    sync = rdist.GradSync(model.parameters(), overlap=True)      # one forward, one backward per step
+    optimizer = optim.Adam(model.parameters(), lr=Init_lr)
+    scheduler = optim.lr_scheduler.MultiStepLR(optimizer, milestones=[500, NUM_EPOCH], gamma=0.1)
+    return pretrain(model, my_dataset, optimizer, scheduler, args.reward_pretrain, config_path, model_save_path,
+                    sync=sync)
+
+
+if __name__ == "__main__":
+    main()

@@ -427,6 +427,89 @@ def ppo_rl_small():
     config.DiscriConfig.update(big)
 
 
+def ppo_reward_grads_small():
+    """Gradients THROUGH the PPO reward model (ppo_policy/model.py:459-495 `LongFormer.token_forward`, the function
+    `my_pretrain.py --reward_pretrain` would train): d(sum of scores * w) / d(every parameter), reference's own class
+    + HF Longformer backward, eval mode (dropout off).  Stored like airl_grads_small: norms of all gradients, the
+    gradients themselves (first 8 rows of large tensors)."""
+    config, model = _import_reference("ppo_policy")
+    config.DiscriConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+    n_token = [49, 19, 19, 89, 67, 25]
+    net = fill_params(model.LongFormer(n_token), seed=33).eval()
+    gen = torch.Generator().manual_seed(80)
+    x = _tokens(gen, (3, 50), n_token)
+    mask = torch.ones(3, 50, dtype=torch.long)
+    mask[2, 41:] = 0
+    w = torch.tensor([[1.0], [-2.0], [0.5]])
+    score = net.token_forward(x, None, mask)
+    (score * w).sum().backward()
+    out = {"x": x.numpy(), "mask": mask.numpy(), "w": w.numpy(), "score": score.detach().numpy(),
+           "n_token": np.array(n_token)}
+    names, norms = [], []
+    for k, p_ in net.named_parameters():
+        if p_.grad is None:
+            continue
+        g = p_.grad.detach()
+        names.append(k)
+        norms.append(g.double().norm().item())
+        out["grad." + k] = (g[:8] if g.numel() > 4096 else g).numpy()
+    out["names"] = np.array(names)
+    out["norms"] = np.array(norms)
+    np.savez_compressed(os.path.join(HERE, "ppo_reward_grads_small.npz"), **out)
+    config.DiscriConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
+
+
+def ppo_dataset_files():
+    """The PPO pipeline's on-disk files written by the REFERENCE's own writers (data, not source):
+      tests/golden/ppo_dataset/dictionary.pickle   <- ppo_policy/prepare_data.py::construct_dict  (:239-302)
+      tests/golden/ppo_dataset/worded_data.pickle   a hand-made input: 4 word sequences of lengths 1300/700/1200/90
+      tests/golden/ppo_dataset/our_dataset.pickle  <- ppo_policy/preprocess.py::process_data      (:10-72), np seed 5
+    prepare_data.py does `import miditoolkit` (absent here) at module level and never touches it inside construct_dict:
+    it gets an empty placeholder module inside this generator only.  process_data reads ./dataset/* relative to the
+    working directory, so it runs in a scratch directory."""
+    import pickle
+    import shutil
+    import tempfile
+    import types
+    out_dir = os.path.join(HERE, "ppo_dataset")
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(REF, "ppo_policy")
+    for m in ("miditoolkit",):
+        sys.modules.setdefault(m, types.ModuleType(m))
+    for m in ("prepare_data", "preprocess", "utils", "chord_recognition", "config"):
+        sys.modules.pop(m, None)
+    sys.path.insert(0, path)
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    try:
+        import contextlib
+        import io
+        prepare_data = importlib.import_module("prepare_data")
+        os.chdir(tmp)
+        os.makedirs("dataset")
+        with contextlib.redirect_stdout(io.StringIO()):
+            prepare_data.construct_dict(os.path.join("dataset", "dictionary.pickle"))
+        with open(os.path.join("dataset", "dictionary.pickle"), "rb") as f:
+            event2word, _ = pickle.load(f)
+        n_tok = [len(event2word[k]) for k in event2word]
+        rng = np.random.default_rng(17)
+        worded = [[[int(rng.integers(0, n - 3)) for n in n_tok] for _ in range(L)] for L in (1300, 700, 1200, 90)]
+        with open(os.path.join("dataset", "worded_data.pickle"), "wb") as f:
+            pickle.dump(worded, f)
+        shutil.copy(os.path.join("dataset", "worded_data.pickle"), os.path.join(out_dir, "worded_data.pickle"))
+        preprocess = importlib.import_module("preprocess")
+        np.random.seed(5)
+        with contextlib.redirect_stdout(io.StringIO()):
+            preprocess.process_data()
+        for name in ("dictionary.pickle", "our_dataset.pickle"):
+            shutil.copy(os.path.join("dataset", name), os.path.join(out_dir, name))
+    finally:
+        os.chdir(cwd)
+        sys.path.remove(path)
+        shutil.rmtree(tmp, ignore_errors=True)
+        sys.modules.pop("config", None)
+
+
 if __name__ == "__main__":
     torch.set_num_threads(4)
     if len(sys.argv) > 1:                      # python make_golden.py <fixture function> ...: only those
@@ -441,6 +524,8 @@ if __name__ == "__main__":
     airl_grads_small()
     dqn_generation_small()
     ppo_rl_small()
+    ppo_reward_grads_small()
+    ppo_dataset_files()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):
             print(f, os.path.getsize(os.path.join(HERE, f)) // 1024, "KiB")
