@@ -57,15 +57,18 @@ int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const vo
  * reverse scan producing dk, dv; forward scan producing dq.  colsum_* (each (N, H*head_dim) f32, may be
  * NULL; bf16 tensors with row strides % 8 == 0 only): per-sequence column sums of the written gradient,
  * i.e. the partial bias gradients of the key / value / query projections (summed over N by the caller),
- * which saves a separate pass over dQ|dK|dV. */
+ * which saves a separate pass over dQ|dK|dV.
+ * dden (N, L, H) f32, may be NULL: dden_l = -(dout_l . out_l) * zinv_l, the gradient through the normaliser.  Both
+ * scans need it; when the caller passes one buffer to both calls (dkdv FIRST), dkdv writes it and dq reads it in place
+ * of the whole `out` stream (bf16 fast path; `out` may then be NULL for dq).  The f32 kernels ignore it. */
 int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, const void* out,
                                 const float* zinv, const void* dout, void* dk, void* dv,
-                                float* colsum_k, float* colsum_v,
+                                float* colsum_k, float* colsum_v, float* dden,
                                 int N, int H, int L, int head_dim,
                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                                 int64_t lddk, int64_t lddv, int dtype, void* stream);
 int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const void* out,
-                              const float* zinv, const void* dout, void* dq, float* colsum_q,
+                              const float* zinv, const void* dout, void* dq, float* colsum_q, const float* dden,
                               int N, int H, int L, int head_dim,
                               int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
                               int64_t lddq, int dtype, void* stream);
@@ -114,15 +117,30 @@ int cwlt_colsum(const void* x, float* part, float* out, int64_t rows, int ncols,
 
 /* ---- FFN activation: g = dropout_p(gelu(h + bias)) ----------------------------------------------
  * Replaces `self.dropout(self.activation(self.linear1(y)))` (activation='gelu' = exact erf,
- * dqn_policy/model.py:134) with the Linear run bias-free.  bias may be NULL.  F % 8 == 0. */
+ * dqn_policy/model.py:134) with the Linear run bias-free.  bias may be NULL.  F % 8 == 0.
+ * gd (rows, F), may be NULL: also write the backward's factor gd = mask * 1/(1-p) * gelu'(h + bias), so that
+ * dh = dg * gd is one multiply in the epilogue of the GEMM that produces dg (cwlt_gemm_nt_mul).  gd may be h itself
+ * (in place: h is then consumed). */
 int cwlt_rowslab_blocks(int64_t rows);
-int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_t rows, int F,
+int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, void* gd, int64_t rows, int F,
                                float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
 /* dh = dropout_bwd(dg) * gelu'(h + bias); dbias (F) f32 = column sums of dh (NULL to skip);
  * part: cwlt_rowslab_blocks(rows)*F f32 (needed iff dbias). */
 int cwlt_bias_gelu_dropout_bwd(const void* dg, const void* h, const float* bias, void* dh,
                                float* part, float* dbias, int64_t rows, int F, float p,
                                uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
+
+/* ---- FFN backward: dh = (dy . W2) * gd with the activation gradient in the GEMM epilogue --------
+ * Replaces, in the backward of fast_transformers' TransformerEncoderLayer (dqn_policy/model.py:128-137), the input
+ * gradient of `linear2` (a GEMM writing dg, rows x d_ff) followed by the backward of dropout(gelu(.)) above: the
+ * product never reaches memory.  a = dy (M, K), w = linear2.weight TRANSPOSED, (N, K) row-major, g = gd (M, N) from
+ * cwlt_bias_gelu_dropout_fwd, c = dh (M, N); all bf16, f32 accumulation, the product rounded to bf16 before the
+ * multiply (the arithmetic of the two-kernel path).  colsum (N) f32 = column sums of c = linear1's bias gradient,
+ * through part (cwlt_gemm_nt_tiles(M) * N floats), both or neither NULL.  N % 256 == 0, K % 64 == 0, row strides
+ * multiples of 8, 16-byte aligned pointers. */
+int64_t cwlt_gemm_nt_tiles(int64_t M);
+int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float* part, float* colsum,
+                     int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldg, int64_t ldc, void* stream);
 
 /* ---- positional encoding + dropout --------------------------------------------------------------
  * y = dropout_p(x + pe[r % T]) -- PositionalEncoding.forward, dqn_policy/model.py:90-92.  pe is the

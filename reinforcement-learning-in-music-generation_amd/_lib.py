@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -44,15 +44,17 @@ _SIGNATURES = {
     "cwlt_causal_linear_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
                                _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr],
     "cwlt_causal_linear_bwd": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
-    "cwlt_causal_linear_bwd_dkdv": [_ptr] * 10 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr],
-    "cwlt_causal_linear_bwd_dq": [_ptr] * 8 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr],
+    "cwlt_causal_linear_bwd_dkdv": [_ptr] * 11 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr],
+    "cwlt_causal_linear_bwd_dq": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr],
     "cwlt_ln_blocks": [_c_i64],
     "cwlt_add_dropout_layernorm_fwd": [_ptr] * 8 + [_c_i64, _c_int, _c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_add_dropout_layernorm_bwd": [_ptr] * 10 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_colsum_blocks": [_c_i64],
     "cwlt_colsum": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_i64, _c_int, _ptr],
     "cwlt_rowslab_blocks": [_c_i64],
-    "cwlt_bias_gelu_dropout_fwd": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
+    "cwlt_bias_gelu_dropout_fwd": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
+    "cwlt_gemm_nt_tiles": [_c_i64],
+    "cwlt_gemm_nt_mul": [_ptr] * 6 + [_c_i64, _c_int, _c_int] + [_c_i64] * 4 + [_ptr],
     "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_ffn1_gelu_dropout_fwd": [_ptr] * 5 + [_c_i64, _c_int, _c_int] + [_c_i64] * 4 + [_c_f32, _c_u64, _ptr, _ptr],
     "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
@@ -104,7 +106,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = _c_i64 if name == "cwlt_decode_workspace_floats" else _c_int
+        fn.restype = _c_i64 if name in ("cwlt_decode_workspace_floats", "cwlt_gemm_nt_tiles") else _c_int
     got = lib.cwlt_abi_version()
     if got != ABI_VERSION:
         raise ImportError("libcwlt.so ABI version %d, binding expects %d -- rebuild" % (got, ABI_VERSION))

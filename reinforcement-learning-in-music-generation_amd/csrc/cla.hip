@@ -517,8 +517,8 @@ int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* ou
 }
 
 int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                                const void* dout, void* dk, void* dv, float* colsum_k, float* colsum_v, int N, int H,
-                                int L, int head_dim,
+                                const void* dout, void* dk, void* dv, float* colsum_k, float* colsum_v, float* dden,
+                                int N, int H, int L, int head_dim,
                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddk,
                                 int64_t lddv, int dtype, void* stream) {
     using namespace cwlt;
@@ -532,14 +532,15 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
     if ((colsum_k == nullptr) != (colsum_v == nullptr)) return CWLT_ERR_ARG;
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo | lddo | lddk | lddv) & 7) == 0;
     if (colsum_k && !fast) return CWLT_ERR_ARG;      // fused column sums exist in the bf16 kernels only
+    if (dden && !fast) return CWLT_ERR_ARG;          // the dden hand-over too
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
         return launch_bwd_dkdv<float>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv,
                                       st);
     if (dtype == CWLT_BF16) {
         if (fast)
-            return launch_cla_bwd_dkdv_bf16(q, k, v, out, zinv, dout, dk, dv, colsum_k, colsum_v, N, H, L, ldq, ldk,
-                                            ldv, ldo, lddo, lddk, lddv, st);
+            return launch_cla_bwd_dkdv_bf16(q, k, v, out, zinv, dout, dk, dv, colsum_k, colsum_v, dden, N, H, L, ldq,
+                                            ldk, ldv, ldo, lddo, lddk, lddv, st);
         return launch_bwd_dkdv<bf16_t>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk,
                                        lddv, st);
     }
@@ -547,25 +548,26 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
 }
 
 int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                              const void* dout, void* dq, float* colsum_q, int N, int H, int L, int head_dim, int64_t ldq,
-                              int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq, int dtype,
-                              void* stream) {
+                              const void* dout, void* dq, float* colsum_q, const float* dden, int N, int H, int L,
+                              int head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                              int64_t lddq, int dtype, void* stream) {
     using namespace cwlt;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;
-    if (!q || !k || !v || !out || !zinv || !dout || !dq) return CWLT_ERR_ARG;
+    if (!q || !k || !v || (!out && !dden) || !zinv || !dout || !dq) return CWLT_ERR_ARG;
     if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H) || bad_ld(lddo, H) || bad_ld(lddq, H))
         return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo | lddo | lddq) & 7) == 0;
     if (colsum_q && !fast) return CWLT_ERR_ARG;      // fused column sums exist in the bf16 kernels only
+    if (dden && !fast) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
         return launch_bwd_dq<float>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
     if (dtype == CWLT_BF16) {
         if (fast)
-            return launch_cla_bwd_dq_bf16(q, k, v, out, zinv, dout, dq, colsum_q, N, H, L, ldq, ldk, ldv, ldo, lddo,
-                                          lddq, st);
+            return launch_cla_bwd_dq_bf16(q, k, v, out, zinv, dout, dden, dq, colsum_q, N, H, L, ldq, ldk, ldv, ldo,
+                                          lddo, lddq, st);
         return launch_bwd_dq<bf16_t>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
     }
     return CWLT_ERR_DTYPE;
@@ -576,11 +578,11 @@ int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const vo
                            const void* dout, void* dq, void* dk, void* dv, int N, int H, int L, int head_dim,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
                            int64_t lddk, int64_t lddv, int dtype, void* stream) {
-    int e = cwlt_causal_linear_bwd_dkdv(q, k, v, out, zinv, dout, dk, dv, nullptr, nullptr, N, H, L, head_dim, ldq, ldk,
-                                        ldv, ldo, lddo, lddk, lddv, dtype, stream);
+    int e = cwlt_causal_linear_bwd_dkdv(q, k, v, out, zinv, dout, dk, dv, nullptr, nullptr, nullptr, N, H, L, head_dim,
+                                        ldq, ldk, ldv, ldo, lddo, lddk, lddv, dtype, stream);
     if (e) return e;
-    return cwlt_causal_linear_bwd_dq(q, k, v, out, zinv, dout, dq, nullptr, N, H, L, head_dim, ldq, ldk, ldv, ldo, lddo,
-                                     lddq, dtype, stream);
+    return cwlt_causal_linear_bwd_dq(q, k, v, out, zinv, dout, dq, nullptr, nullptr, N, H, L, head_dim, ldq, ldk, ldv,
+                                     ldo, lddo, lddq, dtype, stream);
 }
 
 }  // extern "C"

@@ -206,11 +206,14 @@ __device__ __forceinline__ void colsum_store(float (&bsum)[8], float* scratch, f
 //   dqf_i = sum_{j<=i} W_ij kf_j = (W kf)_i + S_prev g_i + dden_i ksum_prev ;  dQ = dqf * phi'(Q)
 // wave (wi, wj): W tile (i-half wi, j-half wj); dq tile (i-half wi, e-half wj).
 // ------------------------------------------------------------------------------------------------
+// HAS_DDEN: dden (N, L, H) f32 was written by the reverse-scan kernel (launched first); the `out` stream -- needed
+// only to rebuild it -- is then not read at all (one of the six 16-byte streams of this kernel).
+template <bool HAS_DDEN>
 __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
-    bf16_t* __restrict__ dq, float* __restrict__ csum, int H, int L, long ldq, long ldk, long ldv, long ldo,
-    long lddo, long lddq) {
+    const float* __restrict__ dden_in, bf16_t* __restrict__ dq, float* __restrict__ csum, int H, int L, long ldq,
+    long ldk, long ldv, long ldo, long lddo, long lddq) {
     __shared__ __attribute__((aligned(16))) bf16_t gs[C * LD];   // g       [i][m]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
@@ -229,12 +232,13 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     const bf16_t* ob = out + ((long)n * L) * ldo + h * D;
     const bf16_t* gb = dout + ((long)n * L) * lddo + h * D;
     const float* zb = zinv + ((long)n * L) * H + h;
+    const float* ddb = HAS_DDEN ? dden_in + ((long)n * L) * H + h : zb;
     bf16_t* dqb = dq + ((long)n * L) * lddq + h * D;
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
     uint4 rq[2], rk[2], rv[2], rg[2], ro[2], rqp[2];
-    float rz[2];
+    float rz[2], rdd[2];
 
     // this stream's rows as buffer resources: rows >= L read back as zeros (hardware range check, no branches)
     const __amdgpu_buffer_rsrc_t qr = make_rsrc(qb, (uint32_t)(((long)(L - 1) * ldq + D) * 2));
@@ -243,6 +247,7 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     const __amdgpu_buffer_rsrc_t gr = make_rsrc(gb, (uint32_t)(((long)(L - 1) * lddo + D) * 2));
     const __amdgpu_buffer_rsrc_t orr = make_rsrc(ob, (uint32_t)(((long)(L - 1) * ldo + D) * 2));
     const __amdgpu_buffer_rsrc_t zr = make_rsrc(zb, (uint32_t)(((long)(L - 1) * H + 1) * 4));
+    const __amdgpu_buffer_rsrc_t ddr = make_rsrc(ddb, (uint32_t)(((long)(L - 1) * H + 1) * 4));
 #define CLA_LOAD(c)                                                                      \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
         const uint32_t row = (uint32_t)(c) * C + srow + 32 * it;                         \
@@ -250,8 +255,11 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
         rk[it] = buf_load16(kr, (row * (uint32_t)ldk + scol) * 2);                       \
         rv[it] = buf_load16(vr, (row * (uint32_t)ldv + scol) * 2);                       \
         rg[it] = buf_load16(gr, (row * (uint32_t)lddo + scol) * 2);                      \
-        ro[it] = buf_load16(orr, (row * (uint32_t)ldo + scol) * 2);                      \
         rz[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, (int)(row * (uint32_t)H * 4), 0, 0)); \
+        if (HAS_DDEN)                                                                    \
+            rdd[it] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ddr, (int)(row * (uint32_t)H * 4), 0, 0)); \
+        else                                                                             \
+            ro[it] = buf_load16(orr, (row * (uint32_t)ldo + scol) * 2);                  \
     }
 #define CLA_STORE(c)                                                                     \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
@@ -285,7 +293,17 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
             const int row = srow + 32 * it;
             const bool ok = c * C + row < L;
             float dden;
-            const uint4 gp = stage_g(rg[it], ro[it], rz[it], dden);
+            uint4 gp;
+            if (HAS_DDEN) {
+                float a[8];
+                unpack8(rg[it], a);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] *= rz[it];
+                gp = pack8(a);
+                dden = rdd[it];
+            } else {
+                gp = stage_g(rg[it], ro[it], rz[it], dden);
+            }
             if ((tid & 7) == 0) dd[row] = dden;
             put_row(gs, row, scol, gp);
             put_row(vs, row, scol, rv[it]);
@@ -349,8 +367,9 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
 __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
-    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, float* __restrict__ csum_k, float* __restrict__ csum_v, int H,
-    int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk, long lddv) {
+    bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, float* __restrict__ csum_k, float* __restrict__ csum_v,
+    float* __restrict__ dden_out, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk,
+    long lddv) {
     __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // phi(q)  [i][e]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
@@ -374,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     const float* zb = zinv + ((long)n * L) * H + h;
     bf16_t* dkb = dk + ((long)n * L) * lddk + h * D;
     bf16_t* dvb = dv + ((long)n * L) * lddv + h * D;
+    float* ddb = dden_out ? dden_out + ((long)n * L) * H + h : nullptr;   // dden for the dq kernel (it then skips `out`)
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
@@ -433,7 +453,10 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
             const bool ok = c * C + row < L;
             float dden;
             const uint4 gp = stage_g(rg[it], ro[it], rz[it], dden);
-            if ((tid & 7) == 0) dd[row] = dden;
+            if ((tid & 7) == 0) {
+                dd[row] = dden;
+                if (ddb && ok) ddb[((long)c * C + row) * H] = dden;
+            }
             put_row(gs, row, scol, gp);
             put_row(vs, row, scol, rv[it]);
             float x[8];
@@ -530,20 +553,26 @@ int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, 
 }
 
 int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                           const void* dout, void* dq, float* csum, int N, int H, int L, long ldq, long ldk, long ldv,
-                           long ldo, long lddo, long lddq, hipStream_t st) {
-    hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dq, csum, H, L, ldq,
-                       ldk, ldv, ldo, lddo, lddq);
+                           const void* dout, const float* dden, void* dq, float* csum, int N, int H, int L, long ldq,
+                           long ldk, long ldv, long ldo, long lddo, long lddq, hipStream_t st) {
+    if (dden)
+        hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel<true>, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, dden,
+                           (bf16_t*)dq, csum, H, L, ldq, ldk, ldv, ldo, lddo, lddq);
+    else
+        hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel<false>, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, dden,
+                           (bf16_t*)dq, csum, H, L, ldq, ldk, ldv, ldo, lddo, lddq);
     return (int)hipGetLastError();
 }
 
 int launch_cla_bwd_dkdv_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                             const void* dout, void* dk, void* dv, float* csum_k, float* csum_v, int N, int H, int L,
-                             long ldq, long ldk, long ldv, long ldo, long lddo, long lddk, long lddv, hipStream_t st) {
+                             const void* dout, void* dk, void* dv, float* csum_k, float* csum_v, float* dden_out,
+                             int N, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk,
+                             long lddv, hipStream_t st) {
     hipLaunchKernelGGL(b16::cla_bwd_dkdv_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dk,
-                       (bf16_t*)dv, csum_k, csum_v, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv);
+                       (bf16_t*)dv, csum_k, csum_v, dden_out, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv);
     return (int)hipGetLastError();
 }
 

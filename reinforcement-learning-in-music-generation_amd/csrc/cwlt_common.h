@@ -206,10 +206,11 @@ int launch_colsum_finalize_multi(const float* part, float* out, long out_stride,
 int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H, int L,
                         long ldq, long ldk, long ldv, long ldo, float eps, hipStream_t st);
 int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                           const void* dout, void* dq, float* csum, int N, int H, int L, long ldq, long ldk, long ldv,
-                           long ldo, long lddo, long lddq, hipStream_t st);
+                           const void* dout, const float* dden, void* dq, float* csum, int N, int H, int L, long ldq,
+                           long ldk, long ldv, long ldo, long lddo, long lddq, hipStream_t st);
 int launch_cla_bwd_dkdv_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
-                             const void* dout, void* dk, void* dv, float* csum_k, float* csum_v, int N, int H, int L,
-                             long ldq, long ldk, long ldv, long ldo, long lddo, long lddk, long lddv, hipStream_t st);
+                             const void* dout, void* dk, void* dv, float* csum_k, float* csum_v, float* dden_out,
+                             int N, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk,
+                             long lddv, hipStream_t st);
 
 }  // namespace cwlt

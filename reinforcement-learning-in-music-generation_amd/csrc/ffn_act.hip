@@ -45,11 +45,13 @@ __device__ __forceinline__ float gelu_grad_f(float x) {
     return cdf + x * pdf;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* __restrict__ h,
-                                                                    const float* __restrict__ bias, T* __restrict__ g,
-                                                                    long rows, int F, uint32_t thresh, float keep_scale,
-                                                                    uint64_t seed,
+// WANT_GD: also write gd = mask * keep_scale * gelu'(h + bias), the factor the backward multiplies the upstream gradient
+// with (consumed by the epilogue of cwlt_gemm_nt_mul).  gd may alias h (each thread reads its chunk of h before it
+// writes the same chunk of gd), which is how the encoder uses it: h itself is not needed again.
+template <typename T, bool WANT_GD>
+__global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* h, const float* __restrict__ bias,
+                                                                    T* __restrict__ g, T* gd, long rows, int F,
+                                                                    uint32_t thresh, float keep_scale, uint64_t seed,
         const uint64_t* __restrict__ seed_base) {
     if (seed_base) seed += *seed_base;   // device-resident offset: lets a captured hipGraph draw fresh masks per replay
     constexpr int V = VecIO<T>::N;
@@ -65,7 +67,7 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* __r
 #pragma unroll 4
     for (long r = r0; r < r1; ++r) {
         const long off = r * F + ci * V;
-        float t[V];
+        float t[V], d[V];
         VecIO<T>::load(h + off, t);
         const uint32_t km = thresh ? dropout_mask<V>(seed, off, thresh) : 0xffffffffu;
         if (FAST) {
@@ -78,15 +80,24 @@ __global__ __launch_bounds__(256) void bias_gelu_dropout_fwd_kernel(const T* __r
                 const f32x2 y = x * cdf * keep_scale;
                 t[j] = ((km >> j) & 1u) ? y[0] : 0.f;
                 t[j + 1] = ((km >> (j + 1)) & 1u) ? y[1] : 0.f;
+                if (WANT_GD) {
+                    const f32x2 dy = (x * pdf + cdf) * keep_scale;
+                    d[j] = ((km >> j) & 1u) ? dy[0] : 0.f;
+                    d[j + 1] = ((km >> (j + 1)) & 1u) ? dy[1] : 0.f;
+                }
             }
         } else {
 #pragma unroll
             for (int j = 0; j < V; ++j) {
-                t[j] = gelu_f<FAST>(t[j] + b[j]);
-                t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
+                const float x = t[j] + b[j];
+                float cdf, pdf;
+                gelu_parts<FAST>(x, cdf, pdf);
+                t[j] = ((km >> j) & 1u) ? x * cdf * keep_scale : 0.f;
+                if (WANT_GD) d[j] = ((km >> j) & 1u) ? (cdf + x * pdf) * keep_scale : 0.f;
             }
         }
         VecIO<T>::store(g + off, t);
+        if (WANT_GD) VecIO<T>::store(gd + off, d);
     }
 }
 
@@ -185,10 +196,10 @@ int cwlt_rowslab_blocks(int64_t rows) {
     return (int)b;
 }
 
-int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_t rows, int F, float p, uint64_t seed,
-                               const uint64_t* seed_base, int dtype, void* stream) {
+int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, void* gd, int64_t rows, int F, float p,
+                               uint64_t seed, const uint64_t* seed_base, int dtype, void* stream) {
     using namespace cwlt;
-    if (!h || !g || rows < 0 || F <= 0 || (F & 7) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (!h || !g || g == h || gd == g || rows < 0 || F <= 0 || (F & 7) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
     if (rows == 0) return CWLT_OK;
     const int vec = dtype == CWLT_BF16 ? 8 : 4;
     // forward has no per-slab partial sums to reduce afterwards: use finer slabs (more loads in flight)
@@ -198,14 +209,17 @@ int cwlt_bias_gelu_dropout_fwd(const void* h, const float* bias, void* g, int64_
     hipStream_t st = (hipStream_t)stream;
     const uint32_t th = drop_thresh(p);
     const float ks = drop_scale(p);
-    if (dtype == CWLT_F32)
-        hipLaunchKernelGGL((bias_gelu_dropout_fwd_kernel<float>), grid, block, 0, st, (const float*)h, bias, (float*)g,
-                           (long)rows, F, th, ks, seed, seed_base);
-    else if (dtype == CWLT_BF16)
-        hipLaunchKernelGGL((bias_gelu_dropout_fwd_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)h, bias,
-                           (bf16_t*)g, (long)rows, F, th, ks, seed, seed_base);
-    else
+#define CWLT_GELU_FWD(T, GD)                                                                                      \
+    hipLaunchKernelGGL((bias_gelu_dropout_fwd_kernel<T, GD>), grid, block, 0, st, (const T*)h, bias, (T*)g, (T*)gd,  \
+                       (long)rows, F, th, ks, seed, seed_base)
+    if (dtype == CWLT_F32) {
+        if (gd) CWLT_GELU_FWD(float, true); else CWLT_GELU_FWD(float, false);
+    } else if (dtype == CWLT_BF16) {
+        if (gd) CWLT_GELU_FWD(bf16_t, true); else CWLT_GELU_FWD(bf16_t, false);
+    } else {
         return CWLT_ERR_DTYPE;
+    }
+#undef CWLT_GELU_FWD
     return (int)hipGetLastError();
 }
 

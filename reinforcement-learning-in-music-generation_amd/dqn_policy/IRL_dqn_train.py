@@ -147,10 +147,11 @@ class DQN(object):
         args = (agent_state, agent_next_state, agent_action, agent_reward, agent_done,
                 expert_next_state.long().cuda(), mask_next_states.float().cuda())
         if ops.train_graphs_enabled():
-            # batch 30 x 50 tokens: ~2 000 small launches per update -- forward, backward and Adam step are
-            # captured once and replayed as one hipGraph (CWLT_GRAPHS=0: eager)
+            # batch 30 x 50 tokens: ~2 000 small launches per update -- with CWLT_TRAIN_GRAPHS=1 forward, backward and
+            # Adam step are captured once and replayed as one hipGraph (opt-in: ops.train_graphs_enabled)
             if getattr(self, "_graph_update", None) is None:
-                self._graph_update = ops.GraphedCall(self._update_device, grad=True)
+                self._graph_update = ops.GraphedCall(self._update_device, grad=True,
+                                                          params=list(self.eval_net.parameters()))
             MSEloss, CEloss, total_loss = self._graph_update(*args)
         else:
             MSEloss, CEloss, total_loss = self._update_device(*args)

@@ -20,6 +20,10 @@ import torch.nn as nn
 from . import ops
 
 
+# CWLT_FUSED_FFN_BWD=0: keep the two-kernel FFN backward (hipBLASLt input-gradient GEMM + cwlt_bias_gelu_dropout_bwd)
+FUSED_FFN_BWD = os.environ.get("CWLT_FUSED_FFN_BWD", "1") != "0"
+
+
 class TriangularCausalMask:
     """fast_transformers.masking.TriangularCausalMask(N, device=...): a lower-triangular marker."""
 
@@ -58,7 +62,11 @@ class _EncoderLayerFn(torch.autograd.Function):
         s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
         del o
         h = torch.mm(x1, w1_a.t())                                         # (R, F)  MFMA, bias in next kernel
-        g = ops.gelu_fwd(h, b1f, p, seeds[1])
+        # bf16, when a backward will follow: the activation kernel overwrites h with gd = mask / (1 - p) * gelu'(h + b1); the backward then needs no
+        # activation pass at all -- dh = (dy . W2) * gd leaves the input-gradient GEMM's epilogue (ops.gemm_nt_mul)
+        fused_ffn = (FUSED_FFN_BWD and adt == torch.bfloat16 and any(ctx.needs_input_grad)
+                     and h.is_contiguous() and h.shape[1] % 256 == 0 and D % 64 == 0)
+        g = ops.gelu_fwd(h, b1f, p, seeds[1], gd_inplace=fused_ffn)
         y = torch.addmm(b2_a, g, w2_a.t())                                 # MFMA
         s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
         del y
@@ -69,6 +77,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         # so they are kept as plain attributes rather than version-checked saved tensors.
         ctx.weights = (wqkv, wo_a, w1_a, w2_a)
         ctx.cfg = (N, L, D, H, p, seeds)
+        ctx.fused_ffn = fused_ffn
         ctx.layer = layer
         return out.view(N, L, D)
 
@@ -95,10 +104,15 @@ class _EncoderLayerFn(torch.autograd.Function):
         def dgrad(g_, w_):
             return torch.mm(g_, w_.t().contiguous().t()) if nt else torch.mm(g_, w_)
 
-        dgact = dgrad(dy, w2_a)                                            # (R, F)
         dw2 = wgrad(dy, g)                                                 # (D, F)
-        dh, db1 = ops.gelu_bwd(dgact, h, b1f, p, seeds[1])
-        del dgact
+        if ctx.fused_ffn:
+            # h holds gd (see forward): input gradient of linear2, activation + dropout backward and linear1's bias
+            # gradient in ONE kernel; dgact (R x F) never reaches memory
+            dh, db1 = ops.gemm_nt_mul(dy, w2_a.t().contiguous(), h)
+        else:
+            dgact = dgrad(dy, w2_a)                                        # (R, F)
+            dh, db1 = ops.gelu_bwd(dgact, h, b1f, p, seeds[1])
+            del dgact
         dx1 = dgrad(dh, w1_a)                                              # (R, D)
         dw1 = wgrad(dh, x1)                                                # (F, D)
         del dh

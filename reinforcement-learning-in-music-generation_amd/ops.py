@@ -124,15 +124,18 @@ def deliver_grad(p, g):
 def deliver_grads(pairs):
     """deliver_grad for a list of (parameter, gradient) pairs with ONE multi-tensor launch instead of one small
     device op per parameter (16 per encoder layer, ~9 us each).  Always an accumulation, as autograd's own
-    AccumulateGrad: the buffers are zeroed by zero_grad().  (An earlier version overwrote on a parameter's first
-    delivery of a step with torch._foreach_copy_; inside a captured training step whose parameters receive two
-    deliveries -- DQN.update runs the network twice -- that combination went wrong when eager GEMMs ran between
-    replays; the accumulate-only form does not.)"""
+    AccumulateGrad: the buffers are zeroed by zero_grad().
+    Never allocates while a hipGraph is being captured: a captured step must find every `.grad` in place (the flat
+    buckets of dist.GradSync) -- a gradient tensor created inside the capture would live in the graph's private
+    pool while `.grad` kept pointing at it from outside; that is refused here instead of being left to chance."""
     dst, src = [], []
     for p, g in pairs:
         if not p.requires_grad:
             continue
         if p.grad is None:
+            if p.is_cuda and torch.cuda.is_current_stream_capturing():
+                raise RuntimeError("deliver_grads under graph capture: a parameter has no .grad buffer yet -- attach "
+                                   "the gradients (dist.GradSync) and run the step eagerly once before capturing it")
             p.grad = g.float().clone() if g.dtype == torch.float32 else g.float()
         else:
             dst.append(p.grad)
@@ -181,18 +184,23 @@ def _seed_base():
 GRAPHS_ENABLED = os.environ.get("CWLT_GRAPHS", "1") != "0"     # CWLT_GRAPHS=0: RL rollout / update steps launch eagerly
 
 
-TRAIN_GRAPHS = os.environ.get("CWLT_TRAIN_GRAPHS", "1") != "0"
+TRAIN_GRAPHS = os.environ.get("CWLT_TRAIN_GRAPHS", "0") == "1"
 
 
 def train_graphs_enabled():
-    """Whole-training-step graphs (forward + backward + Adam of DQN.update / PPO.update_policy in one launch): on
-    unless CWLT_TRAIN_GRAPHS=0 or CWLT_GRAPHS=0, single process only (under data parallelism the gradient all-reduce
-    is launched from the delivery callbacks and stays eager).
-    History: an earlier gradient delivery that OVERWROTE on a parameter's first delivery of a step
-    (torch._foreach_copy_) and accumulated on the second made captured steps whose parameters are delivered
-    twice (DQN.update runs the network twice) go wrong -- NaN losses, once hipErrorIllegalAddress -- as soon as
-    eager GEMMs ran between replays; bisected with tools/diag_graph_{layer,model,update}.py.  The accumulate-only
-    delivery (deliver_grads) does not: 40 replays with interleaved GEMMs and the full IRL_dqn_train loop are clean."""
+    """Whole-training-step graphs (forward + backward + Adam of DQN.update / PPO.update_policy in one launch): OPT-IN
+    with CWLT_TRAIN_GRAPHS=1 (and not CWLT_GRAPHS=0), single process only (under data parallelism the gradient
+    all-reduce stays eager).  The no-grad rollout graphs (GRAPHS_ENABLED) are unaffected and on by default.
+
+    Why opt-in: in round 1 a captured DQN.update produced NaN losses from its third replay on --
+    once hipErrorIllegalAddress -- whenever large eager GEMMs ran between replays.  The change that made it go away
+    (accumulate-only gradient delivery instead of copy-on-first-delivery) is arithmetically equivalent to what it
+    replaced and explains neither symptom; in round 2 neither the old delivery re-created on the current tree
+    (tools/diag_fresh_copy.py) nor the tree that preceded the change, run with its own failing recipe, reproduces
+    the fault on this round's boxes (gpurun_out/r02_diag_*.log).  The cause is therefore NOT known.  What is in
+    place instead of a diagnosis: captured steps never allocate gradient storage (deliver_grads), a captured step
+    checks on every replay that the gradient / parameter storage it was captured against is still where it was
+    (GraphedCall(params=...)), and the feature stays off unless asked for."""
     import torch.distributed as dist
     single = not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1)
     return GRAPHS_ENABLED and TRAIN_GRAPHS and single
@@ -224,9 +232,22 @@ class GraphedCall:
     seed base (a captured op) and launch.  Parameters, gradients and optimizer state are used in place.
     Outputs are the graph's static buffers: valid until the next call with the same signature."""
 
-    def __init__(self, fn, warmup=2, grad=False, eager_calls=2):
+    def __init__(self, fn, warmup=2, grad=False, eager_calls=2, params=None):
         self.fn, self.warmup, self.grad, self.eager_calls = fn, warmup, grad, eager_calls
         self.graphs, self.calls = {}, {}
+        # grad=True: the parameters the step trains.  Their storage and their .grad storage are baked into the graph
+        # as raw addresses; `_storage()` is compared before every replay so that a moved buffer (a dropped / re-made
+        # .grad, a re-allocated parameter) raises instead of letting the graph write through a stale address.
+        self.params = [p for p in params if p.requires_grad] if params is not None else None
+        self._addr = {}
+
+    def _storage(self):
+        if not self.params:
+            return None
+        if any(p.grad is None for p in self.params):
+            raise RuntimeError("GraphedCall(grad=True): a trained parameter has no .grad buffer -- gradients must live "
+                               "in persistent storage (dist.GradSync buckets) before the step is captured")
+        return tuple((p.data_ptr(), p.grad.data_ptr()) for p in self.params)
 
     def _capture(self, args):
         global _USE_SEED_BASE
@@ -246,10 +267,13 @@ class GraphedCall:
                         self.fn(*static)
                 torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
+            before = self._storage()
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph), mode():
                 base.add_(_SEED_STEP)
                 out = self.fn(*static)
+            if self._storage() != before:
+                raise RuntimeError("GraphedCall(grad=True): parameter / gradient storage changed DURING capture")
         finally:
             _USE_SEED_BASE = False
             KernelTimer.enabled = was_timing
@@ -264,7 +288,11 @@ class GraphedCall:
                 self.calls[key] = n + 1
                 return self.fn(*args)
             ent = self.graphs[key] = self._capture(args)
+            self._addr[key] = self._storage()
         graph, static, out = ent
+        if self.params and self._storage() != self._addr[key]:
+            raise RuntimeError("GraphedCall(grad=True): parameter / gradient storage moved since the step was "
+                               "captured (a .grad was dropped or re-created, or a parameter re-allocated)")
         for s, a in zip(static, args):
             s.copy_(a)
         graph.replay()
@@ -378,13 +406,16 @@ def cla_bwd(q, k, v, out, zinv, dout, want_colsum=False):
     ld = 3 * H * D
     common = (_lib.dev(q), _lib.dev(k), _lib.dev(v), _lib.dev(out), _lib.dev(zinv), _lib.dev(dout, "dout"))
     code, st = _lib.dtype_code(q.dtype), _lib.stream_ptr()
-    fused = (want_colsum and q.dtype == torch.bfloat16 and all(x % 8 == 0 for x in (ldq, ldk, ldv, lddo)))
+    fast = q.dtype == torch.bfloat16 and all(x % 8 == 0 for x in (ldq, ldk, ldv, lddo))
+    fused = want_colsum and fast
     cs = torch.empty((3, N, H * D), dtype=torch.float32, device=q.device) if fused else None
+    # dden = -(dout . out) * zinv: written by the reverse scan, read by the dq scan instead of the whole `out` stream
+    dden = torch.empty((N, L, H), dtype=torch.float32, device=q.device) if fast else None
     _call("cwlt_causal_linear_bwd_dkdv", *common, _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]),
-          _lib.dev(cs[1]) if fused else None, _lib.dev(cs[2]) if fused else None, N, H, L, D,
+          _lib.dev(cs[1]) if fused else None, _lib.dev(cs[2]) if fused else None, _lib.opt(dden), N, H, L, D,
           ldq, ldk, ldv, H * D, lddo, ld, ld, code, st)
     _call("cwlt_causal_linear_bwd_dq", *common, _lib.dev(dqkv[:, :, 0]), _lib.dev(cs[0]) if fused else None,
-          N, H, L, D, ldq, ldk, ldv, H * D, lddo, ld, code, st)
+          _lib.opt(dden), N, H, L, D, ldq, ldk, ldv, H * D, lddo, ld, code, st)
     if not want_colsum:
         return dqkv
     if fused:
@@ -485,13 +516,38 @@ def layer_norm(a, gamma, beta, eps=LN_EPS):
 # --------------------------------------------------------------------------------------------------
 # FFN activation, column sums, positional encoding
 # --------------------------------------------------------------------------------------------------
-def gelu_fwd(h, bias, p=0.0, seed=0):
+def gelu_fwd(h, bias, p=0.0, seed=0, gd_inplace=False):
+    """g = dropout(gelu(h + bias)).  gd_inplace: h is OVERWRITTEN with gd = mask / (1 - p) * gelu'(h + bias), the factor
+    the backward multiplies the upstream gradient with (gemm_nt_mul); h itself is gone afterwards."""
     lib = _lib.load()
     rows, F = h.shape
     g = torch.empty_like(h)
-    _call("cwlt_bias_gelu_dropout_fwd", _lib.dev(h, "h"), _lib.opt(bias), _lib.dev(g), rows, F, float(p),
-                                              int(seed), _seed_base(), _lib.dtype_code(h.dtype), _lib.stream_ptr())
+    _call("cwlt_bias_gelu_dropout_fwd", _lib.dev(h, "h"), _lib.opt(bias), _lib.dev(g), _lib.dev(h) if gd_inplace else None,
+          rows, F, float(p), int(seed), _seed_base(), _lib.dtype_code(h.dtype), _lib.stream_ptr())
     return g
+
+
+def gemm_nt_mul_supported(a, w, g):
+    return (a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and g.dtype == torch.bfloat16 and a.dim() == 2
+            and w.dim() == 2 and g.dim() == 2 and w.shape[0] % 256 == 0 and a.shape[1] % 64 == 0
+            and a.shape[1] == w.shape[1] and g.shape == (a.shape[0], w.shape[0])
+            and all(t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in (a, w, g)))
+
+
+def gemm_nt_mul(a, w, g, want_colsum=True):
+    """c = (a @ w.T) * g in one kernel, + column sums of c.  a (M, K), w (N, K), g (M, N) bf16 -> c (M, N) bf16
+    [, colsum (N) f32].  The FFN backward: a = dy, w = linear2.weight.T (contiguous), g = gd."""
+    lib = _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    c = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    part = cs = None
+    if want_colsum:
+        part = torch.empty(lib.cwlt_gemm_nt_tiles(M) * N, dtype=torch.float32, device=a.device)
+        cs = torch.empty(N, dtype=torch.float32, device=a.device)
+    _call("cwlt_gemm_nt_mul", _lib.dev(a, "a"), _lib.dev(w, "w"), _lib.dev(g, "g"), _lib.dev(c), _lib.opt(part),
+          _lib.opt(cs), M, N, K, a.stride(0), w.stride(0), g.stride(0), N, _lib.stream_ptr(), work=2.0 * M * N * K)
+    return (c, cs) if want_colsum else c
 
 
 def ffn1_fused_supported(x, w):

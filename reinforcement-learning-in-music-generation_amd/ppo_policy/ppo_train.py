@@ -152,7 +152,7 @@ class PPO(object):
                 graphs[key] = ops.GraphedCall(
                     lambda st, ol, ad, rt, ex, mk: self._update_rollouts_device(st, ol, list(ad), list(rt), ex, mk,
                                                                                 group, clip) or st.new_zeros(()),
-                    grad=True)
+                    grad=True, params=list(self.actor_net.parameters()) + list(self.critic_net.parameters()))
             graphs[key](states, old_logp_int, torch.stack(list(advs)), torch.stack(list(rets)), expert, mask.float())
             return
         self._update_rollouts_device(states, old_logp_int, advs, rets, expert, mask, group, clip)
@@ -247,7 +247,9 @@ class PPO(object):
                 # 30 x 50-token states: both networks' forward/backward and Adam steps (~4 000 small launches)
                 # are captured once and replayed as one hipGraph per inner step (CWLT_GRAPHS=0: eager)
                 if getattr(self, "_graph_ppo_step", None) is None:
-                    self._graph_ppo_step = ops.GraphedCall(self._ppo_step_device, grad=True)
+                    self._graph_ppo_step = ops.GraphedCall(
+                        self._ppo_step_device, grad=True,
+                        params=list(self.actor_net.parameters()) + list(self.critic_net.parameters()))
                 actor_loss, value_loss = self._graph_ppo_step(*args)
             else:
                 actor_loss, value_loss = self._ppo_step_device(*args)

@@ -191,3 +191,48 @@ def test_posenc_dropout_bf16(cuda, N, T, D, p):
 def test_colsum_bf16(cuda):
     x = _bf(torch.randn(4097, 1536))
     _close(ops.colsum(x.to(cuda)), x.double().sum(0), SUM_TOL, "colsum")
+
+
+@pytest.mark.parametrize("rows", [5, 129, 1000, 4096])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_gelu_fwd_emits_the_backward_factor_in_place(cuda, rows, p):
+    """gd = mask / (1 - p) * gelu'(h + b) written over h by the forward kernel; g unchanged by that option."""
+    g0 = torch.Generator().manual_seed(rows)
+    Fdim = 2048
+    h = _bf(torch.randn(rows, Fdim, generator=g0) * 2)
+    bias = torch.randn(Fdim, generator=g0)
+    seed = 1234
+    keep = _mask_of(rows, Fdim, p, seed, cuda).double() / (1 - p) if p > 0 else 1.0
+    hr = h.double().requires_grad_(True)
+    F.gelu(hr + bias.double()).sum().backward()
+    hd = h.to(cuda)
+    g_plain = ops.gelu_fwd(hd, bias.to(cuda), p, seed)
+    assert torch.equal(hd.cpu(), h)                                  # untouched without the option
+    hd2 = h.to(cuda)
+    g_opt = ops.gelu_fwd(hd2, bias.to(cuda), p, seed, gd_inplace=True)
+    assert torch.equal(g_opt, g_plain)
+    _close(hd2, hr.grad * keep, BF16_TOL, "gd")
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 256, 64), (129, 256, 512), (1000, 2048, 512), (4096, 2048, 512), (7, 512, 128)])
+def test_gemm_nt_mul_epilogue_and_column_sums(cuda, M, N, K):
+    """c = bf16(bf16(a w^T) * g), column sums of c: the FFN backward's fused GEMM vs the f64 chain of the two-kernel
+    path (GEMM result rounded to bf16, then multiplied)."""
+    g0 = torch.Generator().manual_seed(M + N)
+    a = _bf(torch.randn(M, K, generator=g0))
+    w = _bf(torch.randn(N, K, generator=g0) * 0.05)
+    gd = _bf(torch.randn(M, N, generator=g0))
+    assert ops.gemm_nt_mul_supported(a.to(cuda), w.to(cuda), gd.to(cuda))
+    c, cs = ops.gemm_nt_mul(a.to(cuda), w.to(cuda), gd.to(cuda))
+    prod = a.double() @ w.double().t()
+    ref = prod * gd.double()
+    # two bf16 roundings (product, result) of values up to max|prod| * max|gd|
+    scale = max(1.0, prod.abs().max().item() * gd.double().abs().max().item())
+    err = (c.double().cpu() - ref).abs().max().item()
+    assert c.dtype == torch.bfloat16 and err <= 2 * BF16_TOL * scale, (err, scale)
+    _close(cs, c.double().cpu().sum(0), SUM_TOL, "column sums of the stored c")
+    c2 = ops.gemm_nt_mul(a.to(cuda), w.to(cuda), gd.to(cuda), want_colsum=False)
+    assert torch.equal(c2, c)
+    # the unfused pair it replaces: torch.mm -> bf16, times gd
+    unf = (torch.mm(a.to(cuda), w.to(cuda).t()).float() * gd.to(cuda).float()).bfloat16()
+    assert (c.float() - unf.float()).abs().max().item() <= 2 * BF16_TOL * scale

@@ -94,7 +94,42 @@ def bench_gemm_core():
               (N, K, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9))
 
 
+def bench_ffn2_dgrad():
+    """FFN backward: hipBLASLt NT GEMM (dg = dy . W2) + cwlt_bias_gelu_dropout_bwd   vs   cwlt_gemm_nt_mul."""
+    dev = torch.device("cuda:0")
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 524288
+    dy = torch.randn(M, 512, device=dev).bfloat16()
+    w2 = (torch.randn(512, 2048, device=dev) * 0.05).bfloat16()          # linear2.weight (out 512, in 2048)
+    w2t = w2.t().contiguous()                                             # (2048, 512) = [N][K]
+    h = torch.randn(M, 2048, device=dev).bfloat16()
+    b = torch.randn(2048, device=dev) * 0.1
+    t0 = timeit(lambda: torch.mm(dy, w2t.t()))
+    dg = torch.mm(dy, w2t.t())
+    t1 = timeit(lambda: ops.gelu_bwd(dg, h, b, 0.1, 77))
+    t2 = timeit(lambda: ops.gelu_fwd(h, b, 0.1, 77))
+    hh = h.clone()
+    t3 = timeit(lambda: ops.gelu_fwd(hh, b, 0.1, 77, gd_inplace=True))
+    gd = h.clone()
+    ops.gelu_fwd(gd, b, 0.1, 77, gd_inplace=True)
+    t4 = timeit(lambda: ops.gemm_nt_mul(dy, w2t, gd))
+    t5 = timeit(lambda: ops.gemm_nt_mul(dy, w2t, gd, want_colsum=False))
+    fl = 2.0 * M * 512 * 2048
+    by = M * (512 + 2 * 2048) * 2
+    print("M=%d  unfused: mm %.1f us (%.0f TF) + gelu_bwd %.1f us = %.1f us" % (M, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3,
+                                                                             (t0 + t1) * 1e3))
+    print("       fused gemm_nt_mul %.1f us (%.0f TF, %.0f GB/s algorithmic); without column sums %.1f us" %
+          (t4 * 1e3, fl / t4 / 1e9, by / t4 / 1e6, t5 * 1e3))
+    print("       forward activation: plain %.1f us, with gd in place %.1f us (+%.1f)" % (t2 * 1e3, t3 * 1e3,
+                                                                                           (t3 - t2) * 1e3))
+    print("       net per layer: %.1f us saved" % ((t0 + t1 - t4 - (t3 - t2)) * 1e3))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ffn2d":
+        from rlmg_amd import gemm_tuning
+        gemm_tuning.enable()
+        bench_ffn2_dgrad()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "gemmcore":
         from rlmg_amd import gemm_tuning
         gemm_tuning.enable()
