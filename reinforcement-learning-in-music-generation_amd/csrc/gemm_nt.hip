@@ -19,6 +19,7 @@
 // 16-byte coalesced stores.  Operand rows come through buffer resources (hardware range check).  Workgroup ids are
 // dealt so that the column tiles of one row tile run on ONE XCD.
 #include "cwlt_common.h"
+#include <stdlib.h>
 
 namespace cwlt {
 namespace gn {
@@ -35,6 +36,7 @@ __device__ __forceinline__ bf16x8 frag(const bf16_t* t, int row, int k) {
 }
 
 // part: (row tiles, N) f32 column sums of this workgroup's rows of C (NULL: not wanted)
+template <bool NT_STREAMS>
 __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ G, bf16_t* __restrict__ Cout,
     float* __restrict__ part, long M, int N, int K, long lda, long ldw, long ldg, long ldc) {
@@ -118,7 +120,13 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
         make_rsrc(G + m0 * ldg + n0, (uint32_t)(((mrows - 1) * ldg + TNC) * 2));      // rows >= mrows read zeros
     uint4 gv[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) gv[i] = buf_load16(gr, ((uint32_t)(erow + 16 * i) * (uint32_t)ldg + ecol) * 2);
+    for (int i = 0; i < 8; ++i) {
+        // once-read stream: non-temporal (aux = 2) so that it does not evict the operand strips the co-resident
+        // workgroup's main loop re-reads from L2 (CWLT_GEMM_NT=0 builds use the default policy for A/B comparison)
+        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+            gr, (int)(((uint32_t)(erow + 16 * i) * (uint32_t)ldg + ecol) * 2), 0, NT_STREAMS ? 2 : 0);
+        gv[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    }
 
     // f32 product * gd would need the f32 tile in LDS (135 KB); the tile is rounded to bf16 first (as the unfused
     // GEMM's output was) and multiplied in f32, rounded once more: the arithmetic of the two-kernel path.
@@ -152,7 +160,18 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
             t[j] *= gg[j];               // rows past the end: gd read back as zero -> contributes nothing
             cs[j] += t[j];
         }
-        if (row < mrows) store8(Cout + (m0 + row) * ldc + n0 + ecol, t);
+        if (row < mrows) {
+            u32x4_t r;
+            r[0] = f32x2_to_bf16x2(t[0], t[1]);
+            r[1] = f32x2_to_bf16x2(t[2], t[3]);
+            r[2] = f32x2_to_bf16x2(t[4], t[5]);
+            r[3] = f32x2_to_bf16x2(t[6], t[7]);
+            u32x4_t* dst = reinterpret_cast<u32x4_t*>(Cout + (m0 + row) * ldc + n0 + ecol);
+            if (NT_STREAMS)
+                __builtin_nontemporal_store(r, dst);
+            else
+                *dst = r;
+        }
     }
     if (part) {
         // column sums over the tile's 128 rows: 16 threads share a column chunk (erow = 0..15)
@@ -198,9 +217,10 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
     const long mtiles = (M + gn::TMR - 1) / gn::TMR;
     const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
     const long nblk = mt8 * (N / gn::TNC);
-    hipLaunchKernelGGL(gn::gemm_nt_mul_kernel, dim3((unsigned)nblk), dim3(512), 0, st, (const bf16_t*)a,
-                       (const bf16_t*)w, (const bf16_t*)g, (bf16_t*)c, part, (long)M, N, K, (long)lda, (long)ldw,
-                       (long)ldg, (long)ldc);
+    static const bool nts = [] { const char* e = getenv("CWLT_GEMM_NT"); return !(e && e[0] == '0'); }();   // A/B switch
+    hipLaunchKernelGGL(nts ? gn::gemm_nt_mul_kernel<true> : gn::gemm_nt_mul_kernel<false>, dim3((unsigned)nblk),
+                       dim3(512), 0, st, (const bf16_t*)a, (const bf16_t*)w, (const bf16_t*)g, (bf16_t*)c, part,
+                       (long)M, N, K, (long)lda, (long)ldw, (long)ldg, (long)ldc);
     int e = (int)hipGetLastError();
     if (e || !colsum) return e;
     return launch_colsum_finalize(part, colsum, (int)mtiles, (long)N, N, 1.0f, 0, st);
