@@ -39,11 +39,21 @@ int cwlt_abi_version(void);
  * q, k, v, out: (N, L, H, head_dim) with token-row stride ld* elements (head h at column
  * h*head_dim, batch stride L*ld*), RAW projections -- the elu(x)+1 feature map is applied inside.
  * zinv: (N, L, H) f32, 1/(phi(q_l).sum_{j<=l} phi(k_j) + eps), written by fwd, read by bwd.
- * head_dim must be 64 (d_model 512 / 8 heads, dqn_policy/config.py:11-15). */
+ * head_dim must be 64 (d_model 512 / 8 heads, dqn_policy/config.py:11-15).
+ *
+ * Few streams: with N * H far below the 256 CUs one workgroup per (sequence, head) leaves the chip idle (the
+ * reference's own pretrain batch is 4 sequences: dqn_policy/agent_pretrain.py:48).  `segments` > 1 cuts every
+ * sequence into that many runs of whole 64-token chunks, one workgroup each: a first pass reduces each run to its
+ * state increment, a prefix pass turns increments into starting states, the scan proper starts every run from its
+ * state.  cwlt_scan_segments() is the library's choice (1 once the streams fill the chip; bf16 with row strides % 8
+ * == 0 only); seg_ws: cwlt_scan_seg_floats(N, H, segments, backward) floats, NULL when segments == 1.  The backward
+ * calls share ONE workspace: dkdv (first) fills it, dq reads it. */
+int cwlt_scan_segments(int N, int H, int L, int dtype);
+int64_t cwlt_scan_seg_floats(int N, int H, int segments, int backward);
 int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* out, float* zinv,
                            int N, int H, int L, int head_dim,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                           float eps, int dtype, void* stream);
+                           float eps, int segments, float* seg_ws, int dtype, void* stream);
 
 /* dq, dk, dv are gradients w.r.t. the RAW q, k, v (feature-map derivative applied inside);
  * out / zinv are the forward's outputs, dout the gradient w.r.t. out (row stride lddo). */
@@ -55,7 +65,8 @@ int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const vo
 
 /* The two kernels of the backward, separately launchable (the call above = dkdv then dq):
  * reverse scan producing dk, dv; forward scan producing dq.  colsum_* (each (N, H*head_dim) f32, may be
- * NULL; bf16 tensors with row strides % 8 == 0 only): per-sequence column sums of the written gradient,
+ * NULL; bf16 tensors with row strides % 8 == 0 only; (N * segments, H*head_dim) when segments > 1): per-sequence
+ * (per-segment) column sums of the written gradient,
  * i.e. the partial bias gradients of the key / value / query projections (summed over N by the caller),
  * which saves a separate pass over dQ|dK|dV.
  * dden (N, L, H) f32, may be NULL: dden_l = -(dout_l . out_l) * zinv_l, the gradient through the normaliser.  Both
@@ -66,12 +77,12 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
                                 float* colsum_k, float* colsum_v, float* dden,
                                 int N, int H, int L, int head_dim,
                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
-                                int64_t lddk, int64_t lddv, int dtype, void* stream);
+                                int64_t lddk, int64_t lddv, int segments, float* seg_ws, int dtype, void* stream);
 int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const void* out,
                               const float* zinv, const void* dout, void* dq, float* colsum_q, const float* dden,
                               int N, int H, int L, int head_dim,
                               int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
-                              int64_t lddq, int dtype, void* stream);
+                              int64_t lddq, int segments, const float* seg_ws, int dtype, void* stream);
 
 /* ---- fused residual + dropout + LayerNorm ------------------------------------------------------
  * s = x + dropout_p(a) ; y = LayerNorm(s) * gamma + beta.  Replaces, inside fast_transformers'

@@ -41,11 +41,13 @@ class DecodeModel(ctypes.Structure):
 # name -> argtypes; restype is always int (status)
 _SIGNATURES = {
     "cwlt_abi_version": [],
+    "cwlt_scan_segments": [_c_int, _c_int, _c_int, _c_int],
+    "cwlt_scan_seg_floats": [_c_int, _c_int, _c_int, _c_int],
     "cwlt_causal_linear_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
-                               _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr],
+                               _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr, _c_int, _ptr],
     "cwlt_causal_linear_bwd": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
-    "cwlt_causal_linear_bwd_dkdv": [_ptr] * 11 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr],
-    "cwlt_causal_linear_bwd_dq": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr],
+    "cwlt_causal_linear_bwd_dkdv": [_ptr] * 11 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr, _c_int, _ptr],
+    "cwlt_causal_linear_bwd_dq": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr, _c_int, _ptr],
     "cwlt_ln_blocks": [_c_i64],
     "cwlt_add_dropout_layernorm_fwd": [_ptr] * 8 + [_c_i64, _c_int, _c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_add_dropout_layernorm_bwd": [_ptr] * 10 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
@@ -106,7 +108,7 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = _c_i64 if name in ("cwlt_decode_workspace_floats", "cwlt_gemm_nt_tiles") else _c_int
+        fn.restype = _c_i64 if name in ("cwlt_decode_workspace_floats", "cwlt_gemm_nt_tiles", "cwlt_scan_seg_floats") else _c_int
     got = lib.cwlt_abi_version()
     if got != ABI_VERSION:
         raise ImportError("libcwlt.so ABI version %d, binding expects %d -- rebuild" % (got, ABI_VERSION))

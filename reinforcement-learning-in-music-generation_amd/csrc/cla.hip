@@ -497,9 +497,19 @@ static bool bad_ld(long ld, int H) { return ld < (long)H * D || (ld & 3) != 0; }
 
 extern "C" {
 
+int cwlt_scan_segments(int N, int H, int L, int dtype) {
+    if (dtype != CWLT_BF16 || N <= 0 || H <= 0 || L <= 0) return 1;
+    return cwlt::scan_segments(N, H, L);
+}
+
+int64_t cwlt_scan_seg_floats(int N, int H, int segments, int backward) {
+    if (N <= 0 || H <= 0) return 0;
+    return cwlt::scan_seg_floats(N, H, segments, backward);
+}
+
 int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H,
                            int L, int head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float eps,
-                           int dtype, void* stream) {
+                           int segments, float* seg_ws, int dtype, void* stream) {
     using namespace cwlt;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;                     // empty batch / sequence: nothing to do
@@ -507,10 +517,11 @@ int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* ou
     if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H)) return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;
     hipStream_t st = (hipStream_t)stream;
+    const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo) & 7) == 0;
+    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || segments > (L + 63) / 64))) return CWLT_ERR_ARG;
     if (dtype == CWLT_F32) return launch_fwd<float>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
     if (dtype == CWLT_BF16) {
-        if (((ldq | ldk | ldv | ldo) & 7) == 0)
-            return launch_cla_fwd_bf16(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
+        if (fast) return launch_cla_fwd_bf16(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, segments, seg_ws, st);
         return launch_fwd<bf16_t>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
     }
     return CWLT_ERR_DTYPE;
@@ -520,7 +531,7 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
                                 const void* dout, void* dk, void* dv, float* colsum_k, float* colsum_v, float* dden,
                                 int N, int H, int L, int head_dim,
                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddk,
-                                int64_t lddv, int dtype, void* stream) {
+                                int64_t lddv, int segments, float* seg_ws, int dtype, void* stream) {
     using namespace cwlt;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;
@@ -533,6 +544,7 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo | lddo | lddk | lddv) & 7) == 0;
     if (colsum_k && !fast) return CWLT_ERR_ARG;      // fused column sums exist in the bf16 kernels only
     if (dden && !fast) return CWLT_ERR_ARG;          // the dden hand-over too
+    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || segments > (L + 63) / 64))) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
         return launch_bwd_dkdv<float>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv,
@@ -540,7 +552,7 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
     if (dtype == CWLT_BF16) {
         if (fast)
             return launch_cla_bwd_dkdv_bf16(q, k, v, out, zinv, dout, dk, dv, colsum_k, colsum_v, dden, N, H, L, ldq,
-                                            ldk, ldv, ldo, lddo, lddk, lddv, st);
+                                            ldk, ldv, ldo, lddo, lddk, lddv, segments, seg_ws, st);
         return launch_bwd_dkdv<bf16_t>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk,
                                        lddv, st);
     }
@@ -550,7 +562,7 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
 int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const void* out, const float* zinv,
                               const void* dout, void* dq, float* colsum_q, const float* dden, int N, int H, int L,
                               int head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
-                              int64_t lddq, int dtype, void* stream) {
+                              int64_t lddq, int segments, const float* seg_ws, int dtype, void* stream) {
     using namespace cwlt;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;
@@ -561,13 +573,14 @@ int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo | lddo | lddq) & 7) == 0;
     if (colsum_q && !fast) return CWLT_ERR_ARG;      // fused column sums exist in the bf16 kernels only
     if (dden && !fast) return CWLT_ERR_ARG;
+    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || segments > (L + 63) / 64))) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
         return launch_bwd_dq<float>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
     if (dtype == CWLT_BF16) {
         if (fast)
             return launch_cla_bwd_dq_bf16(q, k, v, out, zinv, dout, dden, dq, colsum_q, N, H, L, ldq, ldk, ldv, ldo,
-                                          lddo, lddq, st);
+                                          lddo, lddq, segments, const_cast<float*>(seg_ws), st);
         return launch_bwd_dq<bf16_t>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
     }
     return CWLT_ERR_DTYPE;
@@ -579,10 +592,10 @@ int cwlt_causal_linear_bwd(const void* q, const void* k, const void* v, const vo
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
                            int64_t lddk, int64_t lddv, int dtype, void* stream) {
     int e = cwlt_causal_linear_bwd_dkdv(q, k, v, out, zinv, dout, dk, dv, nullptr, nullptr, nullptr, N, H, L, head_dim,
-                                        ldq, ldk, ldv, ldo, lddo, lddk, lddv, dtype, stream);
+                                        ldq, ldk, ldv, ldo, lddo, lddk, lddv, 1, nullptr, dtype, stream);
     if (e) return e;
     return cwlt_causal_linear_bwd_dq(q, k, v, out, zinv, dout, dq, nullptr, nullptr, N, H, L, head_dim, ldq, ldk, ldv,
-                                     ldo, lddo, lddq, dtype, stream);
+                                     ldo, lddo, lddq, 1, nullptr, dtype, stream);
 }
 
 }  // extern "C"

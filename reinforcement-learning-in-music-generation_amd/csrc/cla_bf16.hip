@@ -35,10 +35,28 @@ __device__ __forceinline__ float dphi(float x) { return x > 0.f ? 1.f : __expf(x
 // forward.  wave (wi, wj): score tile (i-half wi, j-half wj), numerator tile (i-half wi, m-half wj) and
 // half of the normaliser:  den_i = sum_j A~[i][j] * 1 + phi(q_i) . ksum,  ksum = state of the ones column.
 // ------------------------------------------------------------------------------------------------
+// Few streams (N * H below the CU count): the sequence is cut into P segments of `cps` chunks, one workgroup per
+// (stream, segment).  STATE_ONLY workgroups first reduce their segment to its state increment (sum of phi(k)^T v
+// and of phi(k)); seg_prefix_kernel turns the increments into the state each segment starts from; the scan proper
+// then runs every segment from that state.  P == 1: one workgroup per stream, no state traffic (the default).
+// State tiles travel in accumulator-register order ([tile][register][lane] f32), so loading one is 16 coalesced loads.
+__device__ __forceinline__ f32x16 load_tile(const float* t, int lane) {
+    f32x16 x;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) x[r] = t[r * 64 + lane];
+    return x;
+}
+__device__ __forceinline__ void store_tile(float* t, int lane, const f32x16& x) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[r * 64 + lane] = x[r];
+}
+
+template <bool STATE_ONLY>
 __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restrict__ q, const bf16_t* __restrict__ k,
                                                            const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                            float* __restrict__ zinv, int H, int L, long ldq, long ldk,
-                                                           long ldv, long ldo, float eps) {
+                                                           long ldv, long ldo, float eps, int P, int cps,
+                                                           const float* __restrict__ pre, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // phi(q)  [i][e]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
@@ -50,7 +68,8 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = w >> 1, wj = w & 1;
     const int l31 = lane & 31, hf = lane >> 5;
-    const int n = blockIdx.x / H, h = blockIdx.x % H;
+    const int sid = blockIdx.x / P, seg = blockIdx.x % P;      // stream, segment
+    const int n = sid / H, h = sid % H;
     const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
     const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
     const bf16_t* vb = v + ((long)n * L) * ldv + h * D;
@@ -59,6 +78,8 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
+    const int cbeg = seg * cps, cend = min(nch, cbeg + cps);
+    if (cbeg >= nch || (STATE_ONLY && seg == P - 1)) return;   // nothing follows the last segment
     uint4 rq[2], rk[2], rv[2];
     const bf16x8 ones0 = ones_if(l31 == 0);   // A operand: row 0 of the ones block, all k
 
@@ -69,7 +90,7 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
 #define CLA_LOAD(c)                                                                      \
     _Pragma("unroll") for (int it = 0; it < 2; ++it) {                                   \
         const uint32_t row = (uint32_t)(c) * C + srow + 32 * it;                         \
-        rq[it] = buf_load16(qr, (row * (uint32_t)ldq + scol) * 2);                       \
+        if (!STATE_ONLY) rq[it] = buf_load16(qr, (row * (uint32_t)ldq + scol) * 2);      \
         rk[it] = buf_load16(kr, (row * (uint32_t)ldk + scol) * 2);                       \
         rv[it] = buf_load16(vr, (row * (uint32_t)ldv + scol) * 2);                       \
     }
@@ -87,21 +108,29 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
         }                                                                                \
     }
 
-    CLA_LOAD(0);
+    CLA_LOAD(cbeg);
     f32x16 S0 = zero16(), S1 = zero16();  // S[e-half t][m-half wj]: rows e on regs, cols m on lanes
     f32x16 Sa = zero16();                 // ones-column state, e-half wj: Sa[e][0] = ksum[32wj + e]
+    if (!STATE_ONLY && pre && seg > 0) {  // the state this segment starts from (both wi waves hold the same copy)
+        const float* t = pre + (((long)sid * P + seg) * 2 + wj) * (3 * 1024);
+        S0 = load_tile(t, lane);
+        S1 = load_tile(t + 1024, lane);
+        Sa = load_tile(t + 2048, lane);
+    }
 
-    for (int c = 0; c < nch; ++c) {
-        if (c > 0) { CLA_STORE(c - 1); }
+    for (int c = cbeg; c < cend; ++c) {
+        if (!STATE_ONLY && c > cbeg) { CLA_STORE(c - 1); }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int row = srow + 32 * it;
             const bool ok = c * C + row < L;
             float x[8];
-            unpack8(rq[it], x);
+            if (!STATE_ONLY) {
+                unpack8(rq[it], x);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
-            put_row(qs, row, scol, pack8(x));
+                for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+                put_row(qs, row, scol, pack8(x));
+            }
             unpack8(rk[it], x);
 #pragma unroll
             for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
@@ -109,9 +138,10 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
             put_row(vs, row, scol, rv[it]);
         }
         __syncthreads();
-        if (c + 1 < nch) { CLA_LOAD(c + 1); }
+        if (c + 1 < cend) { CLA_LOAD(c + 1); }
 
         // scores as A^T (rows j on regs, cols i on lanes) -> as_[i][j], masked j <= i
+        if (!STATE_ONLY) {
         if (!(wi == 0 && wj == 1)) {
             const f32x16 AT = prod_rows(zero16(), ks, 32 * wj + l31, qs, 32 * wi + l31, 0, 4, hf);
             put_acc_T(as_, 32 * wi + l31, 32 * wj, AT, hf, 0, wi == wj ? l31 : 64, 0.f);
@@ -146,9 +176,11 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
             put_acc_T_f32(os, 32 * wi + l31, 32 * wj, O, hf);
             if (hf == 0) dens[wj][32 * wi + l31] = Oa[0];   // row 0 of the ones block
         }
+        }   // !STATE_ONLY
         // states: S_t[e][m] += sum_j phi(k)[j][32t+e] v[j][32wj+m] ;  Sa[e][0] += sum_j phi(k)[j][32wj+e]
+        // (STATE_ONLY: the two wi waves of a column half split the chunk's four k-steps; their sums are added later)
 #pragma unroll 2
-        for (int s = 0; s < 4; ++s) {
+        for (int s = STATE_ONLY ? 2 * wi : 0; s < (STATE_ONLY ? 2 * wi + 2 : 4); ++s) {
             const bf16x8 b = tfrag8(vs, 16 * s, 32 * wj, lane);
             const bf16x8 a0 = tfrag8(ks, 16 * s, 0, lane);
             const bf16x8 a1 = tfrag8(ks, 16 * s, 32, lane);
@@ -158,9 +190,44 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
         }
         __syncthreads();
     }
-    CLA_STORE(nch - 1);
+    if (STATE_ONLY) {
+        float* t = part + (((long)sid * P + seg) * 4 + w) * (3 * 1024);
+        store_tile(t, lane, S0);
+        store_tile(t + 1024, lane, S1);
+        store_tile(t + 2048, lane, Sa);
+        return;
+    }
+    CLA_STORE(cend - 1);
 #undef CLA_LOAD
 #undef CLA_STORE
+}
+
+// part (streams, P, 4 waves, NT tiles, 1024) f32 -> pre (streams, P, 2 column halves, NT tiles, 1024): tiles
+// [0, nfwd) get the EXCLUSIVE PREFIX over the segments of (wave wj + wave 2 + wj), tiles [nfwd, NT) the exclusive SUFFIX.
+__global__ __launch_bounds__(256) void seg_prefix_kernel(const float* __restrict__ part, float* __restrict__ pre,
+                                                         long total, int P, int NT, int nfwd) {
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;    // over (stream, wj, tile, element)
+    if (i >= total) return;
+    const int e = (int)(i & 1023);
+    const int tile = (int)((i >> 10) % NT);
+    const int wj = (int)((i >> 10) / NT) & 1;
+    const long sid = (i >> 10) / NT / 2;
+    const long pstride = (long)4 * NT * 1024, ostride = (long)2 * NT * 1024;
+    const float* a = part + sid * P * pstride + ((long)wj * NT + tile) * 1024 + e;          // wave (0, wj)
+    const float* b = a + (long)2 * NT * 1024;                                               // wave (1, wj)
+    float* o = pre + sid * P * ostride + ((long)wj * NT + tile) * 1024 + e;
+    float run = 0.f;
+    if (tile < nfwd) {
+        for (int p = 0; p < P; ++p) {
+            o[p * ostride] = run;
+            if (p < P - 1) run += a[p * pstride] + b[p * pstride];
+        }
+    } else {
+        for (int p = P - 1; p >= 0; --p) {
+            o[p * ostride] = run;
+            if (p > 0) run += a[p * pstride] + b[p * pstride];
+        }
+    }
 }
 
 // Common staging of the backward kernels for one (row, 8-column) slot:
@@ -213,7 +280,7 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
     const float* __restrict__ dden_in, bf16_t* __restrict__ dq, float* __restrict__ csum, int H, int L, long ldq,
-    long ldk, long ldv, long ldo, long lddo, long lddq) {
+    long ldk, long ldv, long ldo, long lddo, long lddq, int P, int cps, const float* __restrict__ pre) {
     __shared__ __attribute__((aligned(16))) bf16_t gs[C * LD];   // g       [i][m]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
@@ -225,7 +292,8 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = w >> 1, wj = w & 1;
     const int l31 = lane & 31, hf = lane >> 5;
-    const int n = blockIdx.x / H, h = blockIdx.x % H;
+    const int sid = blockIdx.x / P, seg = blockIdx.x % P;      // stream, segment (P == 1: whole sequences)
+    const int n = sid / H, h = sid % H;
     const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
     const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
     const bf16_t* vb = v + ((long)n * L) * ldv + h * D;
@@ -237,6 +305,8 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
+    const int cbeg = seg * cps, cend = min(nch, cbeg + cps);
+    if (cbeg >= nch) return;
     uint4 rq[2], rk[2], rv[2], rg[2], ro[2], rqp[2];
     float rz[2], rdd[2];
 
@@ -281,13 +351,19 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
     float bsum[8];   // column sums of dQ over this stream (bias gradient of the query projection)
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsum[j] = 0.f;
-    CLA_LOAD(0);
+    CLA_LOAD(cbeg);
     f32x16 T0 = zero16(), T1 = zero16();  // ST_t[m][e] = S[32wj+e][32t+m]: rows m on regs, cols e on lanes
     f32x16 Ta = zero16();                 // ones row: Ta[0][e] = ksum[32wj + e]
+    if (pre && seg > 0) {                 // prefix state of this segment: tiles 0..2 of the backward's 8
+        const float* t = pre + (((long)sid * P + seg) * 2 + wj) * (8 * 1024);
+        T0 = load_tile(t, lane);
+        T1 = load_tile(t + 1024, lane);
+        Ta = load_tile(t + 2048, lane);
+    }
     const bf16x8 ones0 = ones_if(l31 == 0);
 
-    for (int c = 0; c < nch; ++c) {
-        if (c > 0) { CLA_STORE(c - 1); }
+    for (int c = cbeg; c < cend; ++c) {
+        if (c > cbeg) { CLA_STORE(c - 1); }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int row = srow + 32 * it;
@@ -315,7 +391,7 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
             rqp[it] = rq[it];
         }
         __syncthreads();
-        if (c + 1 < nch) { CLA_LOAD(c + 1); }
+        if (c + 1 < cend) { CLA_LOAD(c + 1); }
 
         const float dden_i = dd[32 * wi + l31];
         // W^T (rows j on regs, cols i on lanes) = v g^T  (+ dden_i) -> ws[i][j], masked j <= i
@@ -351,10 +427,10 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
         }
         __syncthreads();
     }
-    CLA_STORE(nch - 1);
+    CLA_STORE(cend - 1);
 #undef CLA_LOAD
 #undef CLA_STORE
-    if (csum) colsum_store(bsum, os, csum + ((long)n * H + h) * D, tid, lane, w);
+    if (csum) colsum_store(bsum, os, csum + (((long)n * P + seg) * H + h) * D, tid, lane, w);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -364,12 +440,15 @@ __global__ __launch_bounds__(256) void cla_bwd_dq_bf16_kernel(
 //   R[e][m] = sum_{i later} qf_i[e] g_i[m],  r1[e] = sum_{i later} qf_i[e] dden_i
 // wave (wi, wj): W and A tiles (i-half wi, j-half wj); dk tile (j-half wi, e-half wj); dv tile (j-half wi, m-half wj).
 // ------------------------------------------------------------------------------------------------
+// STATE_ONLY (few streams, see the forward kernel): the segment's increments of ALL backward states, 8 tiles per
+// wave -- [0..2] the dq scan's ST_0, ST_1, ones row (from k, v), [3..7] this kernel's RT_0, RT_1, RTa, R2_0, R2_1.
+template <bool STATE_ONLY>
 __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
     const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
     bf16_t* __restrict__ dk, bf16_t* __restrict__ dv, float* __restrict__ csum_k, float* __restrict__ csum_v,
     float* __restrict__ dden_out, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk,
-    long lddv) {
+    long lddv, int P, int cps, const float* __restrict__ pre, float* __restrict__ part) {
     __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // phi(q)  [i][e]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
@@ -384,7 +463,8 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = w >> 1, wj = w & 1;
     const int l31 = lane & 31, hf = lane >> 5;
-    const int n = blockIdx.x / H, h = blockIdx.x % H;
+    const int sid = blockIdx.x / P, seg = blockIdx.x % P;      // stream, segment (P == 1: whole sequences)
+    const int n = sid / H, h = sid % H;
     const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
     const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
     const bf16_t* vb = v + ((long)n * L) * ldv + h * D;
@@ -397,6 +477,8 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
 
     const int srow = tid >> 3, scol = (tid & 7) * 8;
     const int nch = (L + C - 1) / C;
+    const int cbeg = seg * cps, cend = min(nch, cbeg + cps);
+    if (cbeg >= nch) return;
     uint4 rq[2], rk[2], rv[2], rg[2], ro[2];
     float rz[2];
 
@@ -440,13 +522,23 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
 #pragma unroll
     for (int j = 0; j < 8; ++j) bsk[j] = bsv[j] = 0.f;
 
-    CLA_LOAD(nch - 1);
+    CLA_LOAD(cend - 1);
     f32x16 RT0 = zero16(), RT1 = zero16();  // RT_t[m][e] = R[32wj+e][32t+m]: rows m on regs, cols e on lanes
     f32x16 RTa = zero16();                  // RTa[0][e] = r1[32wj + e]
     f32x16 R20 = zero16(), R21 = zero16();  // R2_t[e][m] = R[32t+e][32wj+m]: rows e on regs, cols m on lanes
+    f32x16 T0 = zero16(), T1 = zero16(), Ta = zero16();   // STATE_ONLY: the dq scan's states (its kernel's layout)
+    const bf16x8 ones0 = ones_if(l31 == 0);
+    if (!STATE_ONLY && pre && seg < P - 1) {              // suffix state of this segment: tiles 3..7
+        const float* t = pre + (((long)sid * P + seg) * 2 + wj) * (8 * 1024) + 3 * 1024;
+        RT0 = load_tile(t, lane);
+        RT1 = load_tile(t + 1024, lane);
+        RTa = load_tile(t + 2048, lane);
+        R20 = load_tile(t + 3072, lane);
+        R21 = load_tile(t + 4096, lane);
+    }
 
-    for (int c = nch - 1; c >= 0; --c) {
-        if (c < nch - 1) { CLA_STORE(c + 1); }
+    for (int c = cend - 1; c >= cbeg; --c) {
+        if (!STATE_ONLY && c < cend - 1) { CLA_STORE(c + 1); }
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
             const int row = srow + 32 * it;
@@ -455,7 +547,7 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
             const uint4 gp = stage_g(rg[it], ro[it], rz[it], dden);
             if ((tid & 7) == 0) {
                 dd[row] = dden;
-                if (ddb && ok) ddb[((long)c * C + row) * H] = dden;
+                if (!STATE_ONLY && ddb && ok) ddb[((long)c * C + row) * H] = dden;
             }
             put_row(gs, row, scol, gp);
             put_row(vs, row, scol, rv[it]);
@@ -470,8 +562,9 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
             put_row(qs, row, scol, pack8(x));
         }
         __syncthreads();
-        if (c > 0) { CLA_LOAD(c - 1); }
+        if (c > cbeg) { CLA_LOAD(c - 1); }
 
+        if (!STATE_ONLY) {
         // W and A tiles (rows i on regs, cols j on lanes), kept where i >= j, written transposed: wt[j][i], at[j][i]
         if (!(wi == 0 && wj == 1)) {
             f32x16 W = prod_rows(zero16(), gs, 32 * wi + l31, vs, 32 * wj + l31, 0, 4, hf);
@@ -507,10 +600,12 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
             V = prod_accA(V, R20, R21, ks, 32 * wi + l31, hf);
             put_acc_T(ov, 32 * wi + l31, 32 * wj, V, hf, 0, 64, 0.f);
         }
+        }   // !STATE_ONLY
         // RT_t[m][e] += sum_i g[i][32t+m] qf[i][32wj+e] ; RTa[0][e] += sum_i dden_i qf[i][32wj+e]
         // R2_t[e][m] += sum_i qf[i][32t+e] g[i][32wj+m]
+        // (STATE_ONLY: the two wi waves of a column half split the chunk's four k-steps)
 #pragma unroll 2
-        for (int s = 0; s < 4; ++s) {
+        for (int s = STATE_ONLY ? 2 * wi : 0; s < (STATE_ONLY ? 2 * wi + 2 : 4); ++s) {
             const bf16x8 g0 = tfrag8(gs, 16 * s, 0, lane), g1 = tfrag8(gs, 16 * s, 32, lane);
             const bf16x8 q0 = tfrag8(qs, 16 * s, 0, lane), q1 = tfrag8(qs, 16 * s, 32, lane);
             const bf16x8 bq = wj == 0 ? q0 : q1;
@@ -530,49 +625,133 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
             }
             RTa = mfma(dh, bq, RTa);
             RTa = mfma(dl, bq, RTa);
+            if (STATE_ONLY) {
+                // the dq scan's states over the same tokens: ST_t[m][e] += sum_j v[j][32t+m] kf[j][32wj+e] ; ones row
+                const bf16x8 bk = tfrag8(ks, 16 * s, 32 * wj, lane);
+                T0 = mfma(tfrag8(vs, 16 * s, 0, lane), bk, T0);
+                T1 = mfma(tfrag8(vs, 16 * s, 32, lane), bk, T1);
+                Ta = mfma(ones0, bk, Ta);
+            }
         }
         __syncthreads();
     }
-    CLA_STORE(0);
+    if (STATE_ONLY) {
+        float* t = part + (((long)sid * P + seg) * 4 + w) * (8 * 1024);
+        store_tile(t, lane, T0);
+        store_tile(t + 1024, lane, T1);
+        store_tile(t + 2048, lane, Ta);
+        store_tile(t + 3072, lane, RT0);
+        store_tile(t + 4096, lane, RT1);
+        store_tile(t + 5120, lane, RTa);
+        store_tile(t + 6144, lane, R20);
+        store_tile(t + 7168, lane, R21);
+        return;
+    }
+    CLA_STORE(cbeg);
 #undef CLA_LOAD
 #undef CLA_STORE
     if (csum_k) {
         float* scratch = reinterpret_cast<float*>(wt);   // score tiles are dead after the loop
-        colsum_store(bsk, scratch, csum_k + ((long)n * H + h) * D, tid, lane, w);
-        colsum_store(bsv, scratch, csum_v + ((long)n * H + h) * D, tid, lane, w);
+        colsum_store(bsk, scratch, csum_k + (((long)n * P + seg) * H + h) * D, tid, lane, w);
+        colsum_store(bsv, scratch, csum_v + (((long)n * P + seg) * H + h) * D, tid, lane, w);
     }
 }
 
+
+
 }  // namespace b16
 
+// Segment count for few-stream launches: 1 (one workgroup per stream) once N * H fills the chip; otherwise enough
+// segments for ~2 workgroups per CU, at least two chunks each, at most 16.
+int scan_segments(int N, int H, int L) {
+    const long streams = (long)N * H;
+    const int nch = (L + b16::C - 1) / b16::C;
+    if (streams >= 256 || nch < 4) return 1;
+    long want = (512 + streams - 1) / streams;
+    if (want > 16) want = 16;
+    if (want > nch / 2) want = nch / 2;
+    if (want < 2) return 1;
+    const int cps = (nch + (int)want - 1) / (int)want;
+    return (nch + cps - 1) / cps;                      // no empty segment
+}
+static int seg_cps(int L, int P) { return (((L + b16::C - 1) / b16::C) + P - 1) / P; }
+
+long scan_seg_floats(int N, int H, int P, int backward) {
+    return P > 1 ? (long)N * H * P * 6 * (backward ? 8 : 3) * 1024 : 0;
+}
+
 int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H, int L,
-                        long ldq, long ldk, long ldv, long ldo, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q, (const bf16_t*)k,
-                       (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps);
+                        long ldq, long ldk, long ldv, long ldo, float eps, int P, float* ws, hipStream_t st) {
+    const int nch = (L + b16::C - 1) / b16::C;
+    if (P <= 1) {
+        hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel<false>, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps, 1, nch,
+                           (const float*)nullptr, (float*)nullptr);
+        return (int)hipGetLastError();
+    }
+    const int cps = seg_cps(L, P);
+    const long NS = (long)N * H;
+    float* part = ws;
+    float* pre = ws + NS * P * 4 * 3 * 1024;
+    hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel<true>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps, P, cps,
+                       (const float*)nullptr, part);
+    const long total = NS * 2 * 3 * 1024;
+    hipLaunchKernelGGL(b16::seg_prefix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, pre, total,
+                       P, 3, 3);
+    hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel<false>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps, P, cps,
+                       (const float*)pre, (float*)nullptr);
     return (int)hipGetLastError();
 }
 
+// P > 1: `ws` must be the workspace launch_cla_bwd_dkdv_bf16 has just filled (it computes the prefix states of both scans)
 int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
                            const void* dout, const float* dden, void* dq, float* csum, int N, int H, int L, long ldq,
-                           long ldk, long ldv, long ldo, long lddo, long lddq, hipStream_t st) {
+                           long ldk, long ldv, long ldo, long lddo, long lddq, int P, float* ws, hipStream_t st) {
+    const int nch = (L + b16::C - 1) / b16::C;
+    const long NS = (long)N * H;
+    const int cps = P > 1 ? seg_cps(L, P) : nch;
+    const float* pre = P > 1 ? ws + NS * P * 4 * 8 * 1024 : nullptr;
+    if (P < 1) P = 1;
     if (dden)
-        hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel<true>, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
+        hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel<true>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, dden,
-                           (bf16_t*)dq, csum, H, L, ldq, ldk, ldv, ldo, lddo, lddq);
+                           (bf16_t*)dq, csum, H, L, ldq, ldk, ldv, ldo, lddo, lddq, P, cps, pre);
     else
-        hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel<false>, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
+        hipLaunchKernelGGL(b16::cla_bwd_dq_bf16_kernel<false>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, dden,
-                           (bf16_t*)dq, csum, H, L, ldq, ldk, ldv, ldo, lddo, lddq);
+                           (bf16_t*)dq, csum, H, L, ldq, ldk, ldv, ldo, lddo, lddq, P, cps, pre);
     return (int)hipGetLastError();
 }
 
 int launch_cla_bwd_dkdv_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
                              const void* dout, void* dk, void* dv, float* csum_k, float* csum_v, float* dden_out,
                              int N, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk,
-                             long lddv, hipStream_t st) {
-    hipLaunchKernelGGL(b16::cla_bwd_dkdv_bf16_kernel, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
+                             long lddv, int P, float* ws, hipStream_t st) {
+    const int nch = (L + b16::C - 1) / b16::C;
+    const long NS = (long)N * H;
+    if (P <= 1) {
+        hipLaunchKernelGGL(b16::cla_bwd_dkdv_bf16_kernel<false>, dim3(NS), dim3(256), 0, st, (const bf16_t*)q,
+                           (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv,
+                           (bf16_t*)dk, (bf16_t*)dv, csum_k, csum_v, dden_out, H, L, ldq, ldk, ldv, ldo, lddo, lddk,
+                           lddv, 1, nch, (const float*)nullptr, (float*)nullptr);
+        return (int)hipGetLastError();
+    }
+    const int cps = seg_cps(L, P);
+    float* part = ws;
+    float* pre = ws + NS * P * 4 * 8 * 1024;
+    hipLaunchKernelGGL(b16::cla_bwd_dkdv_bf16_kernel<true>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dk,
-                       (bf16_t*)dv, csum_k, csum_v, dden_out, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv);
+                       (bf16_t*)dv, (float*)nullptr, (float*)nullptr, (float*)nullptr, H, L, ldq, ldk, ldv, ldo, lddo,
+                       lddk, lddv, P, cps, (const float*)nullptr, part);
+    const long total = NS * 2 * 8 * 1024;
+    hipLaunchKernelGGL(b16::seg_prefix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, pre, total,
+                       P, 8, 3);
+    hipLaunchKernelGGL(b16::cla_bwd_dkdv_bf16_kernel<false>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, (bf16_t*)dk,
+                       (bf16_t*)dv, csum_k, csum_v, dden_out, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv, P, cps,
+                       (const float*)pre, (float*)nullptr);
     return (int)hipGetLastError();
 }
 

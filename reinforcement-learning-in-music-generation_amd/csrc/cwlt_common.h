@@ -202,15 +202,18 @@ int launch_colsum_finalize_multi(const float* part, float* out, long out_stride,
                                  int ncols, hipStream_t st);
 
 
-// bf16 throughput path of the causal linear attention (cla_bf16.hip); row strides must be multiples of 8
+// bf16 throughput path of the causal linear attention (cla_bf16.hip); row strides must be multiples of 8.
+// P = segments per stream (scan_segments: 1 unless N * H is far below the CU count), ws = scan_seg_floats(...) floats.
+int scan_segments(int N, int H, int L);
+long scan_seg_floats(int N, int H, int P, int backward);
 int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H, int L,
-                        long ldq, long ldk, long ldv, long ldo, float eps, hipStream_t st);
+                        long ldq, long ldk, long ldv, long ldo, float eps, int P, float* ws, hipStream_t st);
 int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
                            const void* dout, const float* dden, void* dq, float* csum, int N, int H, int L, long ldq,
-                           long ldk, long ldv, long ldo, long lddo, long lddq, hipStream_t st);
+                           long ldk, long ldv, long ldo, long lddo, long lddq, int P, float* ws, hipStream_t st);
 int launch_cla_bwd_dkdv_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
                              const void* dout, void* dk, void* dv, float* csum_k, float* csum_v, float* dden_out,
                              int N, int H, int L, long ldq, long ldk, long ldv, long ldo, long lddo, long lddk,
-                             long lddv, hipStream_t st);
+                             long lddv, int P, float* ws, hipStream_t st);
 
 }  // namespace cwlt

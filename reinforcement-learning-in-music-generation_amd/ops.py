@@ -375,6 +375,27 @@ class ShadowSet:
 # --------------------------------------------------------------------------------------------------
 # causal linear attention
 # --------------------------------------------------------------------------------------------------
+def scan_segments(N, H, L, dtype, ld_ok=True):
+    """Segments per stream the scan kernels should use (1 unless N * H is far below the CU count; bf16 only).
+    CWLT_SCAN_SEGMENTS=<n> forces a count (tests, A/B runs): clipped to the number of 64-token chunks."""
+    if dtype != torch.bfloat16 or not ld_ok or N * L == 0:
+        return 1
+    forced = os.environ.get("CWLT_SCAN_SEGMENTS")
+    if forced:
+        nch = (L + 63) // 64
+        want = max(1, min(int(forced), nch))
+        cps = -(-nch // want)
+        return -(-nch // cps)
+    return int(_lib.load().cwlt_scan_segments(N, H, L, _lib.dtype_code(dtype)))
+
+
+def _seg_ws(N, H, P, backward, device):
+    if P <= 1:
+        return None
+    n = int(_lib.load().cwlt_scan_seg_floats(N, H, P, 1 if backward else 0))
+    return torch.empty(n, dtype=torch.float32, device=device)
+
+
 def cla_fwd(q, k, v, eps=CLA_EPS):
     """q, k, v: (N, L, H, 64) views (row-strided ok) -> out (N, L, H, 64) dense, zinv (N, L, H) f32."""
     lib = _lib.load()
@@ -388,8 +409,10 @@ def cla_fwd(q, k, v, eps=CLA_EPS):
     v, ldv = _as_rows(v)
     out = torch.empty((N, L, H, D), dtype=q.dtype, device=q.device)
     zinv = torch.empty((N, L, H), dtype=torch.float32, device=q.device)
+    P = scan_segments(N, H, L, q.dtype, all(x % 8 == 0 for x in (ldq, ldk, ldv)))
+    ws = _seg_ws(N, H, P, False, q.device)
     _call("cwlt_causal_linear_fwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.dev(out), _lib.dev(zinv),
-        N, H, L, D, ldq, ldk, ldv, H * D, float(eps), _lib.dtype_code(q.dtype), _lib.stream_ptr())
+        N, H, L, D, ldq, ldk, ldv, H * D, float(eps), P, _lib.opt(ws), _lib.dtype_code(q.dtype), _lib.stream_ptr())
     return q, k, v, out, zinv
 
 
@@ -408,18 +431,20 @@ def cla_bwd(q, k, v, out, zinv, dout, want_colsum=False):
     code, st = _lib.dtype_code(q.dtype), _lib.stream_ptr()
     fast = q.dtype == torch.bfloat16 and all(x % 8 == 0 for x in (ldq, ldk, ldv, lddo))
     fused = want_colsum and fast
-    cs = torch.empty((3, N, H * D), dtype=torch.float32, device=q.device) if fused else None
+    P = scan_segments(N, H, L, q.dtype, fast)
+    ws = _seg_ws(N, H, P, True, q.device)          # shared by the two calls: dkdv fills it, dq reads it
+    cs = torch.empty((3, N * P, H * D), dtype=torch.float32, device=q.device) if fused else None
     # dden = -(dout . out) * zinv: written by the reverse scan, read by the dq scan instead of the whole `out` stream
     dden = torch.empty((N, L, H), dtype=torch.float32, device=q.device) if fast else None
     _call("cwlt_causal_linear_bwd_dkdv", *common, _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]),
           _lib.dev(cs[1]) if fused else None, _lib.dev(cs[2]) if fused else None, _lib.opt(dden), N, H, L, D,
-          ldq, ldk, ldv, H * D, lddo, ld, ld, code, st)
+          ldq, ldk, ldv, H * D, lddo, ld, ld, P, _lib.opt(ws), code, st)
     _call("cwlt_causal_linear_bwd_dq", *common, _lib.dev(dqkv[:, :, 0]), _lib.dev(cs[0]) if fused else None,
-          _lib.opt(dden), N, H, L, D, ldq, ldk, ldv, H * D, lddo, ld, code, st)
+          _lib.opt(dden), N, H, L, D, ldq, ldk, ldv, H * D, lddo, ld, P, _lib.opt(ws), code, st)
     if not want_colsum:
         return dqkv
     if fused:
-        dbias = cs.sum(1).reshape(3 * H * D) if N > 1 else cs.reshape(3 * H * D)
+        dbias = cs.sum(1).reshape(3 * H * D) if N * P > 1 else cs.reshape(3 * H * D)
     else:
         dbias = colsum(dqkv.view(N * L, 3 * H * D))
     return dqkv, dbias

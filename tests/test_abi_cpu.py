@@ -44,9 +44,9 @@ def test_argument_validation_without_gpu(built):
     """Entry points refuse bad arguments before touching the device."""
     lib = built.load()
     null = ctypes.c_void_p(0)
-    assert lib.cwlt_causal_linear_fwd(null, null, null, null, null, 1, 8, 16, 64, 512, 512, 512, 512, 1e-6, 0, null) == 1001
+    assert lib.cwlt_causal_linear_fwd(null, null, null, null, null, 1, 8, 16, 64, 512, 512, 512, 512, 1e-6, 1, null, 0, null) == 1001
     buf = ctypes.c_void_p(16)   # non-null dummy; rejected on head_dim before any launch
-    assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 0, null) == 1001
+    assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 1, null, 0, null) == 1001
     assert lib.cwlt_add_dropout_layernorm_fwd(null, null, null, null, null, null, null, null, 4, 512, 1e-5, 0.0, 0, null, 0, null) == 1001
     assert lib.cwlt_ln_blocks(65536) == 1024 and lib.cwlt_ln_blocks(1) == 1
     # weight-gradient split counts: ~one workgroup per CU in multiples of 8 at training sizes, slices of >= 256 token
@@ -54,6 +54,11 @@ def test_argument_validation_without_gpu(built):
     assert lib.cwlt_wgrad_splits(524288, 2048, 512) == 16 and lib.cwlt_wgrad_splits(524288, 512, 512) == 64
     assert lib.cwlt_wgrad_splits(1500, 2048, 512) == 5 and lib.cwlt_wgrad_splits(32, 256, 256) == 1
     assert lib.cwlt_wgrad_splits(4096, 2048, 512) == 16
+    # scan segments: one workgroup per stream once N * H fills the chip; the reference's own batch (4 x 8 streams of
+    # 3584 tokens = 56 chunks) is cut into 14 runs of 4 chunks; f32 (dtype 0) never
+    assert lib.cwlt_scan_segments(512, 8, 1024, 1) == 1 and lib.cwlt_scan_segments(4, 8, 3584, 1) == 14
+    assert lib.cwlt_scan_segments(4, 8, 3584, 0) == 1 and lib.cwlt_scan_segments(1, 8, 50, 1) == 1
+    assert lib.cwlt_scan_seg_floats(4, 8, 14, 0) == 4 * 8 * 14 * 6 * 3 * 1024 and lib.cwlt_scan_seg_floats(4, 8, 1, 1) == 0
     assert lib.cwlt_sample_categorical(buf, (ctypes.c_int * 2)(5, 300), None, None, 2, 1, 305, 0, null, buf, null, 0, null) == 1001
     # generation step: an incomplete model description is refused before any launch
     m = built.DecodeModel()

@@ -27,15 +27,21 @@ def test_scan_is_linear_in_values_at_full_size(cuda, dtype, tol):
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_scan_is_causal_and_batch_independent_at_full_size(cuda, dtype):
+def test_scan_is_causal_and_batch_independent_at_full_size(cuda, dtype, monkeypatch):
     x = _qkv(dtype, 2, cuda)
     a = ops.causal_linear_attention(x[:, :, 0], x[:, :, 1], x[:, :, 2])
     y = x.clone()
     y[:, 700:, 1:] = torch.randn_like(y[:, 700:, 1:])          # change k, v from token 700 on
     b = ops.causal_linear_attention(y[:, :, 0], y[:, :, 1], y[:, :, 2])
     assert torch.equal(a[:, :700], b[:, :700]) and not torch.equal(a[:, 700:], b[:, 700:])
-    c = ops.causal_linear_attention(x[5:9, :, 0], x[5:9, :, 1], x[5:9, :, 2])   # sequences are independent streams
-    assert torch.equal(c, a[5:9])
+    # sequences are independent streams: a sub-batch gives the same rows.  4 sequences x 8 heads is a few-stream launch,
+    # which the bf16 kernels run cut into segments (other summation order of the chunk states): bitwise equality holds
+    # schedule for schedule, a fraction of a bf16 ulp across schedules
+    c = ops.causal_linear_attention(x[5:9, :, 0], x[5:9, :, 1], x[5:9, :, 2])
+    assert (c.float() - a[5:9].float()).abs().max().item() <= 2.0 ** -8 * max(1.0, a.float().abs().max().item())
+    monkeypatch.setenv("CWLT_SCAN_SEGMENTS", "1")
+    c1 = ops.causal_linear_attention(x[5:9, :, 0], x[5:9, :, 1], x[5:9, :, 2])
+    assert torch.equal(c1, a[5:9])
 
 
 def test_scan_constant_values_give_constant_output(cuda):
