@@ -8,8 +8,8 @@
 //   * 256 x 256 output tile per workgroup (16 waves as 4 x 4, each wave 64 x 64 = 4 MFMA 32x32x16 tiles),
 //     so A is re-read N2/256 times and B N1/256 times only;
 //   * the reduction runs over the ROW index of both operands, i.e. both MFMA operands are needed
-//     transposed: tiles are staged row-major (16-B coalesced loads, 576-B LDS rows) and fragments are
-//     fetched with ds_read_b64_tr_b16 -- conflict-free at this row stride;
+//     transposed: tiles are staged row-major straight into LDS (LDS-DMA, 512-B rows, XOR-swizzled on the source
+//     side) and fragments are fetched with ds_read_b64_tr_b16 -- conflict-free under that swizzle;
 //   * the token dimension is split over blockIdx.z so that ~256-512 workgroups exist; every split writes
 //     an f32 partial tile and a fixed-order reduce kernel sums them straight into the f32 gradient
 //     buffer (deterministic, no atomics, no bf16 rounding of the gradient).
@@ -19,20 +19,35 @@ namespace cwlt {
 namespace wg {
 
 constexpr int TM = 256, TN = 256, BK = 32;
-constexpr int LDW = 288;  // LDS row stride in bf16 (576 B = 144 banks = 16 mod 64)
+constexpr int NSTAGE = 4;                 // LDS ring: 4 x (32 x 256 A rows + 32 x 256 B rows) bf16 = 128 KiB
+constexpr int ROW = 256;                  // LDS row = 256 bf16 = 512 B, unpadded (LDS-DMA writes 1 KiB = two whole rows)
+constexpr int OPB = BK * ROW * 2;         // bytes of one operand stage (16 KiB)
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) void lds_void;
 
 __device__ __forceinline__ constexpr int acc_row(int r, int hf) { return (r & 3) + 8 * (r >> 2) + 4 * hf; }
 
-// X[l&31][8h + j] = T[k0 + 8h + j][c0 + (l&31)], T row-major with stride LDW
-__device__ __forceinline__ bf16x8 tfrag(const bf16_t* t, int k0, int c0, int lane) {
+// Staging goes global -> LDS directly (buffer_load_dwordx4 ... lds: no VGPR round trip, no ds_write -- the 16-byte
+// LDS stores of the register-staged version cost ~13 LDS cycles per wave-instruction and, with the fragment reads,
+// kept the LDS pipe busier than the MFMA pipe).  An LDS-DMA wave-instruction writes 1 KiB linearly, so rows are
+// unpadded 512 B; bank conflicts of the transposed fragment reads (4 consecutive rows, same 64-byte column block =
+// same banks at this stride) are avoided by an XOR swizzle applied on the SOURCE side: the 16-byte chunk c of row r
+// is stored at chunk position c ^ ((r & 3) << 2), i.e. 64-byte block b of row r sits at block b ^ (r & 3).
+//
+// byte offset (inside one operand stage) of the transposed-fragment read of this lane: X[l&31][8h + j] = T[k0 + 8h + j]
+// [c0 + (l&31)] for k0 = 0; k0 = 16 adds 16 rows (the swizzle depends on row & 3 only)
+__device__ __forceinline__ int tfrag_off(int c0, int lane) {
     const int q = (lane >> 2) & 3, p = lane & 3;
-    const bf16_t* base = t + (k0 + 8 * (lane >> 5) + q) * LDW + c0 + 16 * ((lane >> 4) & 1) + 4 * p;
+    const int row = 8 * (lane >> 5) + q;
+    const int chunk = (c0 >> 3) + 2 * ((lane >> 4) & 1) + (p >> 1);
+    return (row * ROW + ((chunk ^ (q << 2)) << 3) + 4 * (p & 1)) * 2;
+}
+__device__ __forceinline__ bf16x8 tfrag_at(const char* base) {
     const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base));
-    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * LDW));
+    const s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(base + 4 * ROW * 2));
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
@@ -40,8 +55,7 @@ template <bool EDGE>
 __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       float* __restrict__ part, long M, int N1, int N2, long lda,
                                                       long ldb, long mslice) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[2][BK * LDW];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][BK * LDW];
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // NSTAGE x [A stage | B stage]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);   // 16 waves as 4 x 4, each 64 x 64
@@ -69,9 +83,6 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     const bf16_t* Ab = A + (long)t1 * TM;
     const bf16_t* Bb = B + (long)t2 * TN;
 
-    const int srow = tid >> 5, scol = (tid & 31) * 8;   // one 16-B slot of the 32 x 256 stage per thread
-    uint4 ra0, rb0, ra1, rb1;   // two register stages: global loads run two steps ahead
-
     // the slice's rows [m0, m1) of both operands as buffer resources: rows past the slice end read back as zeros
     // (hardware range check), offsets are 32-bit and relative to the slice start
     // An edge tile narrower than 256 columns reads on into the next row (finite data whose products land in output
@@ -79,27 +90,65 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     const long nrow = m1 > m0 ? m1 - m0 : 0;
     const long a_lim = min((nrow - 1) * lda + TM, (M - m0 - 1) * lda + (N1 - t1 * TM));
     const long b_lim = min((nrow - 1) * ldb + TN, (M - m0 - 1) * ldb + (N2 - t2 * TN));
-    const __amdgpu_buffer_rsrc_t ar = make_rsrc(Ab + m0 * lda, nrow ? (uint32_t)(a_lim * 2) : 0u);
-    const __amdgpu_buffer_rsrc_t br = make_rsrc(Bb + m0 * ldb, nrow ? (uint32_t)(b_lim * 2) : 0u);
-#define WG_LOAD(RA, RB, ms)                                                                \
-    {                                                                                      \
-        const uint32_t row = (uint32_t)((ms) - m0) + srow;                                 \
-        RA = buf_load16(ar, (row * (uint32_t)lda + scol) * 2);                             \
-        RB = buf_load16(br, (row * (uint32_t)ldb + scol) * 2);                             \
+    // descriptors as four SGPRs each (built from wave-uniform values only; readfirstlane makes that provable)
+    const uint64_t abase = (uint64_t)(Ab + m0 * lda), bbase = (uint64_t)(Bb + m0 * ldb);
+    u32x4_t ars, brs;
+    ars[0] = __builtin_amdgcn_readfirstlane((uint32_t)abase);
+    ars[1] = __builtin_amdgcn_readfirstlane((uint32_t)(abase >> 32));
+    ars[2] = __builtin_amdgcn_readfirstlane(nrow ? (uint32_t)(a_lim * 2) : 0u);
+    ars[3] = 0x00020000u;
+    brs[0] = __builtin_amdgcn_readfirstlane((uint32_t)bbase);
+    brs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(bbase >> 32));
+    brs[2] = __builtin_amdgcn_readfirstlane(nrow ? (uint32_t)(b_lim * 2) : 0u);
+    brs[3] = 0x00020000u;
+
+    // this wave's two DMA pieces per step: rows 2w, 2w + 1 of the A stage and of the B stage.  Lane l lands at
+    // piece base + 16 l = (row 2w + (l >> 5), chunk position l & 31), which holds chunk (l & 31) ^ ((row & 3) << 2).
+    const int drow = 2 * w + hf;
+    const int dchunk = l31 ^ ((drow & 3) << 2);
+    const uint32_t a_voff = ((uint32_t)drow * (uint32_t)lda + dchunk * 8) * 2;
+    const uint32_t b_voff = ((uint32_t)drow * (uint32_t)ldb + dchunk * 8) * 2;
+    const uint32_t a_step = (uint32_t)(BK * lda * 2), b_step = (uint32_t)(BK * ldb * 2);   // bytes per 32-row step
+    // The two pieces are issued from inline asm: through the builtin, hipcc (ROCm 7.2) cannot tell which LDS bytes a
+    // DMA writes and drains ALL of them (s_waitcnt vmcnt(0)) before the first fragment read of every step, which
+    // serialises the ring.  Here the waits are counted by hand (vmcnt(4) below).  M0 carries the LDS address and
+    // is compiler-reserved: saved and restored inside the statement; s_nop: SGPR write -> M0 / VMEM-read hazards.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)lds + w * 1024;      // this wave's piece inside a stage
+#define WG_DMA(stage, step)                                                                                       \
+    {                                                                                                             \
+        unsigned keep;                                                                                            \
+        const uint32_t la = lds0 + (uint32_t)(stage) * (2 * OPB);                                                 \
+        const uint32_t sa = (uint32_t)(step) * a_step, sb_ = (uint32_t)(step) * b_step;                           \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"                                     \
+                     "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"                                               \
+                     "s_add_u32 m0, %3, 0x4000\n\ts_nop 0\n\t"                                                   \
+                     "buffer_load_dwordx4 %5, %6, %7 offen lds\n\t"                                               \
+                     "s_mov_b32 m0, %0"                                                                           \
+                     : "=&s"(keep)                                                                                \
+                     : "v"(a_voff), "s"(ars), "s"(la), "s"(sa), "v"(b_voff), "s"(brs), "s"(sb_)                   \
+                     : "memory", "scc");                                                                          \
     }
-#define WG_STAGE(RA, RB, buf)                                                              \
+    // fragment read offsets of this lane inside a stage (k0 = 0; the second k-step adds 16 rows)
+    const int oa0 = tfrag_off(64 * wn1, lane), oa1 = tfrag_off(64 * wn1 + 32, lane);
+    const int ob0 = OPB + tfrag_off(64 * wn2, lane), ob1 = OPB + tfrag_off(64 * wn2 + 32, lane);
+    // all 16 fragment reads of the step are issued first (both k-steps, distinct registers), so the second k-step's
+    // LDS latency hides behind the first one's MFMAs instead of being waited for after them
+#define WG_COMPUTE(stage)                                                                  \
     {                                                                                      \
-        *reinterpret_cast<uint4*>(&As[buf][srow * LDW + scol]) = RA;                       \
-        *reinterpret_cast<uint4*>(&Bs[buf][srow * LDW + scol]) = RB;                       \
-    }
-#define WG_COMPUTE(buf)                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                               \
-        bf16x8 a[2], b[2];                                                                 \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) a[i] = tfrag(As[buf], 16 * ks, 64 * wn1 + 32 * i, lane); \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) b[j] = tfrag(Bs[buf], 16 * ks, 64 * wn2 + 32 * j, lane); \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                      \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                  \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0); \
+        const char* sb = lds + (stage) * (2 * OPB);                                        \
+        constexpr int ko = 16 * ROW * 2;                                                   \
+        const bf16x8 a0 = tfrag_at(sb + oa0), b0 = tfrag_at(sb + ob0);                     \
+        const bf16x8 a1 = tfrag_at(sb + oa1), b1 = tfrag_at(sb + ob1);                     \
+        const bf16x8 c0_ = tfrag_at(sb + oa0 + ko), d0_ = tfrag_at(sb + ob0 + ko);         \
+        const bf16x8 c1_ = tfrag_at(sb + oa1 + ko), d1_ = tfrag_at(sb + ob1 + ko);         \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);   \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);   \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);   \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0_, d0_, acc[0][0], 0, 0, 0); \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0_, d1_, acc[0][1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1_, d0_, acc[1][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1_, d1_, acc[1][1], 0, 0, 0); \
     }
 
     f32x16 acc[2][2];
@@ -110,28 +159,25 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // prologue: step 0 -> LDS[0]; step 1 in register stage 0
-    WG_LOAD(ra0, rb0, m0);
-    WG_STAGE(ra0, rb0, 0);
-    WG_LOAD(ra0, rb0, m0 + BK);
-    __syncthreads();
-    // steady state, unrolled by two so both register stages keep static names (a register rotation would
-    // make every iteration wait for its NEWEST loads); slices are padded to an even number of steps
-    // (rows past the slice end load zeros).
-    //   even step: compute LDS[0]; loads for step+2 -> stage 1; stage 0 (step+1) -> LDS[1]
-    //   odd  step: compute LDS[1]; loads for step+2 -> stage 0; stage 1 (step+1) -> LDS[0]
-    for (long ms = m0; ms < m1; ms += 2 * BK) {
-        WG_LOAD(ra1, rb1, ms + 2 * BK);
-        WG_COMPUTE(0);
-        WG_STAGE(ra0, rb0, 1);
-        __syncthreads();
-        WG_LOAD(ra0, rb0, ms + 3 * BK);
-        WG_COMPUTE(1);
-        WG_STAGE(ra1, rb1, 0);
-        __syncthreads();
+    // Ring of NSTAGE = 4 stages, DMA running 3 steps ahead.  Per step ONE barrier:
+    //   wait until this wave's pieces of step s have landed (vmcnt leaves the 2 younger steps = 4 pieces in flight);
+    //   barrier: every wave's pieces of step s have landed, and every wave has finished reading step s - 1;
+    //   issue step s + 3 into the stage step s - 1 used;  compute step s.
+    // Steps past the slice end load zeros (range check), so the tail needs no special case: the slice is padded to
+    // a whole number of steps and the last three issued steps are never computed.
+    const int nstep = (int)((mslice + BK - 1) / BK);
+    WG_DMA(0, 0);
+    WG_DMA(1, 1);
+    WG_DMA(2, 2);
+    for (int s = 0; s < nstep; ++s) {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        WG_DMA((s + 3) & 3, s + 3);
+        WG_COMPUTE(s & 3);
     }
-#undef WG_LOAD
-#undef WG_STAGE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // pieces still in flight target LDS: drain before exit
+#undef WG_DMA
 #undef WG_COMPUTE
     const int r0 = t1 * TM + 64 * wn1, c0 = t2 * TN + 64 * wn2 + l31;
     float* pb = part + ((long)slice * N1 + r0) * N2 + c0;
@@ -202,10 +248,21 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
     const int S = cwlt_wgrad_splits(M, N1, N2);
     if (S <= 0) return CWLT_ERR_ARG;
     long mslice = (M + S - 1) / S;
-    mslice = (mslice + 2 * wg::BK - 1) / (2 * wg::BK) * (2 * wg::BK);   // even number of BK steps
+    mslice = (mslice + wg::BK - 1) / wg::BK * wg::BK;                   // whole 32-row steps
     hipStream_t st = (hipStream_t)stream;
     const bool edge = (N1 & 255) || (N2 & 255);
-    hipLaunchKernelGGL(edge ? wg::wgrad_kernel<true> : wg::wgrad_kernel<false>, dim3(((N1 + 255) / 256) * ((N2 + 255) / 256) * S), dim3(1024), 0, st, (const bf16_t*)a,
+    constexpr int lds_bytes = wg::NSTAGE * 2 * wg::OPB;                 // 128 KiB: above the 64 KiB default limit
+    static const int lds_ok = [] {
+        int e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         lds_bytes);
+        if (!e)
+            e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        return e;
+    }();
+    if (lds_ok) return lds_ok;
+    hipLaunchKernelGGL(edge ? wg::wgrad_kernel<true> : wg::wgrad_kernel<false>,
+                       dim3(((N1 + 255) / 256) * ((N2 + 255) / 256) * S), dim3(1024), lds_bytes, st, (const bf16_t*)a,
                        (const bf16_t*)b, part, (long)M, N1, N2, (long)lda, (long)ldb, mslice);
     int e = (int)hipGetLastError();
     if (e) return e;
