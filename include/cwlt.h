@@ -110,15 +110,6 @@ int cwlt_add_dropout_layernorm_bwd(const void* dy, const void* dy2, const void* 
                                    int64_t rows, int D, float p, uint64_t seed, const uint64_t* seed_base,
                                    int dtype, void* stream);
 
-/* ---- FFN inner projection with the activation fused into the GEMM epilogue (bf16) --------------------
- * h (M, N) = x (M, K) . w (N, K)^T  and  g = dropout_p(gelu(h + bias)) in one kernel: replaces linear1 + F.gelu +
- * dropout of fast_transformers' TransformerEncoderLayer.forward (dqn_policy/model.py:128-137), i.e. one GEMM plus
- * cwlt_bias_gelu_dropout_fwd.  Same arithmetic and dropout keys as that pair.  bf16 operands / outputs, bias (N) f32;
- * N % 256 == 0, K % 64 == 0, row strides multiples of 8 elements, 16-byte aligned pointers. */
-int cwlt_ffn1_gelu_dropout_fwd(const void* x, const void* w, const float* bias, void* h, void* g,
-                               int64_t M, int N, int K, int64_t ldx, int64_t ldw, int64_t ldh, int64_t ldg,
-                               float p, uint64_t seed, const uint64_t* seed_base, void* stream);
-
 /* ---- deterministic column sums (bias gradients) -------------------------------------------------
  * out[c] = sum_r x[r*ld + c]; part: cwlt_colsum_blocks(rows)*ncols f32.  Replaces the reductions
  * autograd runs for nn.Linear bias gradients (dqn_policy/model.py:123,156-161). */

@@ -1,5 +1,5 @@
 // Exact-erf GELU pieces for the bf16 paths (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7), shared by the
-// elementwise kernels (ffn_act.hip) and the fused FFN GEMM epilogues (ffn_gemm.hip).
+// elementwise kernels (ffn_act.hip).
 #pragma once
 #include "cwlt_common.h"
 

@@ -575,24 +575,6 @@ def gemm_nt_mul(a, w, g, want_colsum=True):
     return (c, cs) if want_colsum else c
 
 
-def ffn1_fused_supported(x, w):
-    return (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x.dim() == 2 and w.dim() == 2
-            and w.shape[0] % 256 == 0 and x.shape[1] % 64 == 0 and x.stride(1) == 1 and w.stride(1) == 1
-            and x.stride(0) % 8 == 0 and w.stride(0) % 8 == 0 and x.data_ptr() % 16 == 0 and w.data_ptr() % 16 == 0)
-
-
-def ffn1_fused(x, w, bias, p=0.0, seed=0):
-    """h = x @ w.T ; g = dropout(gelu(h + bias)) in ONE kernel (GEMM with the activation in its epilogue).
-    x (rows, K), w (F, K) bf16, bias (F) f32 -> h, g (rows, F) bf16."""
-    rows, K = x.shape
-    F = w.shape[0]
-    h = torch.empty((rows, F), dtype=x.dtype, device=x.device)
-    g = torch.empty_like(h)
-    _call("cwlt_ffn1_gelu_dropout_fwd", _lib.dev(x, "x"), _lib.dev(w, "w"), _lib.dev(bias), _lib.dev(h), _lib.dev(g),
-          rows, F, K, x.stride(0), w.stride(0), F, F, float(p), int(seed), _seed_base(), _lib.stream_ptr())
-    return h, g
-
-
 def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
     lib = _lib.load()
     rows, F = h.shape

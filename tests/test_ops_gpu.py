@@ -201,20 +201,3 @@ def test_heads_bf16_logits(cuda):
         o += n
     out = ops.heads_ce(logits.to(cuda), target.to(cuda), mask.to(cuda), n_class)
     _close(out, torch.stack(ref), tol=1e-5, what="bf16 losses")
-
-
-def test_ffn1_fused_gemm_matches_gemm_plus_gelu(cuda):
-    """Experimental fused FFN1 GEMM (h = x W^T, g = dropout(gelu(h + b)) from the epilogue): h equals the library
-    GEMM to a bf16 ulp, g is bit-identical to the separate activation kernel applied to that h; ragged rows."""
-    g = torch.Generator().manual_seed(21)
-    for rows in (1000, 129, 4096):
-        x = torch.randn(rows, 512, generator=g).bfloat16().to(cuda)
-        w = (torch.randn(2048, 512, generator=g) * 0.05).bfloat16().to(cuda)
-        b = (torch.randn(2048, generator=g) * 0.1).to(cuda)
-        assert ops.ffn1_fused_supported(x, w)
-        h, gg = ops.ffn1_fused(x, w, b, 0.1, 4242)
-        ref = torch.mm(x.float(), w.float().t())
-        assert (h.float() - ref).abs().max().item() <= 2.0 ** -7 * max(1.0, ref.abs().max().item())
-        assert torch.equal(gg, ops.gelu_fwd(h, b, 0.1, 4242))
-        h0, g0 = ops.ffn1_fused(x, w, b, 0.0, 0)
-        assert torch.equal(h0, h) and torch.equal(g0, ops.gelu_fwd(h, b, 0.0, 0))

@@ -57,43 +57,6 @@ def bench_wgrad():
               (N1, N2, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9))
 
 
-def bench_ffn1():
-    dev = torch.device("cuda:0")
-    M = int(sys.argv[2]) if len(sys.argv) > 2 else 262144
-    x = torch.randn(M, 512, device=dev).bfloat16()
-    w = (torch.randn(2048, 512, device=dev) * 0.05).bfloat16()
-    b = torch.randn(2048, device=dev) * 0.1
-    h0 = torch.mm(x, w.t())
-    g0 = ops.gelu_fwd(h0, b, 0.1, 77)
-    h1, g1 = ops.ffn1_fused(x, w, b, 0.1, 77)
-    print("h: max |fused - hipBLASLt| = %.3e (max |h| %.2f); mismatching bf16 values: %.4f %%" %
-          ((h1.float() - h0.float()).abs().max().item(), h0.float().abs().max().item(),
-           100.0 * (h1 != h0).float().mean().item()))
-    g1ref = ops.gelu_fwd(h1, b, 0.1, 77)
-    print("g vs the separate kernel applied to the fused h: identical = %s" % torch.equal(g1, g1ref))
-    t0 = timeit(lambda: torch.mm(x, w.t()))
-    t1 = timeit(lambda: ops.gelu_fwd(h0, b, 0.1, 77))
-    t2 = timeit(lambda: ops.ffn1_fused(x, w, b, 0.1, 77))
-    fl = 2.0 * M * 512 * 2048
-    print("hipBLASLt mm %.1f us (%.0f TF) + gelu %.1f us = %.1f us ; fused %.1f us (%.0f TF on the GEMM flops)" %
-          (t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, (t0 + t1) * 1e3, t2 * 1e3, fl / t2 / 1e9))
-
-
-def bench_gemm_core():
-    """The fused-FFN kernel's GEMM core on the model's other forward shapes vs torch.mm (it writes two outputs)."""
-    dev = torch.device("cuda:0")
-    M = 262144
-    for N, K in ((2048, 512), (512, 2048), (512, 512), (1536, 512)):
-        x = torch.randn(M, K, device=dev).bfloat16()
-        w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
-        b = torch.zeros(N, device=dev)
-        t0 = timeit(lambda: torch.mm(x, w.t()))
-        t1 = timeit(lambda: ops.ffn1_fused(x, w, b, 0.0, 0))
-        fl = 2.0 * M * N * K
-        print("N=%4d K=%4d  torch.mm %7.1f us (%5.0f TF)   cwlt core + 2 outputs %7.1f us (%5.0f TF)" %
-              (N, K, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, fl / t1 / 1e9))
-
-
 def bench_ffn2_dgrad():
     """FFN backward: hipBLASLt NT GEMM (dg = dy . W2) + cwlt_bias_gelu_dropout_bwd   vs   cwlt_gemm_nt_mul."""
     dev = torch.device("cuda:0")
@@ -129,16 +92,6 @@ if __name__ == "__main__":
         from rlmg_amd import gemm_tuning
         gemm_tuning.enable()
         bench_ffn2_dgrad()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "gemmcore":
-        from rlmg_amd import gemm_tuning
-        gemm_tuning.enable()
-        bench_gemm_core()
-        sys.exit(0)
-    if len(sys.argv) > 1 and sys.argv[1] == "ffn1":
-        from rlmg_amd import gemm_tuning
-        gemm_tuning.enable()
-        bench_ffn1()
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "wgrad":
         bench_wgrad()

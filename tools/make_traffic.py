@@ -19,7 +19,8 @@ ENTRY = [("cla_fwd_bf16_kernel", "cwlt_causal_linear_fwd"), ("cla_bwd_dq_bf16_ke
          ("add_dropout_ln_bwd_kernel", "cwlt_add_dropout_layernorm_bwd"), ("bias_gelu_dropout_fwd_kernel", "cwlt_bias_gelu_dropout_fwd"),
          ("bias_gelu_dropout_bwd_kernel", "cwlt_bias_gelu_dropout_bwd"), ("wgrad_kernel", "cwlt_wgrad_bf16"),
          ("wgrad_reduce_kernel", "cwlt_wgrad_bf16"), ("cw_embed_bwd", "cwlt_cw_embed_bwd"), ("cw_embed_fwd", "cwlt_cw_embed_fwd"),
-         ("heads_fwd", "cwlt_heads_fwd"), ("heads_ce_bwd", "cwlt_heads_ce_bwd"), ("posenc_dropout_kernel", "cwlt_posenc_dropout")]
+         ("heads_fwd", "cwlt_heads_fwd"), ("heads_ce_bwd", "cwlt_heads_ce_bwd"), ("posenc_dropout_kernel", "cwlt_posenc_dropout"),
+         ("gemm_nt_mul_kernel", "cwlt_gemm_nt_mul")]
 MAIN = {"cwlt_wgrad_bf16": "wgrad_kernel"}      # launches counted by the main kernel of multi-kernel entry points
 
 
@@ -48,6 +49,9 @@ def main():
     for ent in sorted(ft):
         if fn[ent] and wn.get(ent):
             out[ent] = int(round((2.0 * ft[ent] / fn[ent] + wt[ent] / wn[ent]) * 1024))
+    # the attention backward as bench.py prices it: ONE unit per attention call = its two launches together
+    if "cwlt_causal_linear_bwd_dkdv" in out and "cwlt_causal_linear_bwd_dq" in out:
+        out["cwlt_causal_linear_bwd"] = out["cwlt_causal_linear_bwd_dkdv"] + out["cwlt_causal_linear_bwd_dq"]
     meta = {"batch": int(sys.argv[3]) if len(sys.argv) > 3 else 512, "seq": 1024, "dtype": "bf16",
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1; "
                       "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 FETCH_SIZE half-count correction for 16-B "
