@@ -39,7 +39,8 @@ def synth_batch(B, T, seed, device):
 
 
 SCAN_BWD = "cwlt_causal_linear_bwd"              # the backward of one attention call, however many launches it takes
-SCAN_BWD_PARTS = ("cwlt_causal_linear_bwd", "cwlt_causal_linear_bwd_dkdv", "cwlt_causal_linear_bwd_dq")
+SCAN_BWD_PARTS = ("cwlt_causal_linear_bwd", "cwlt_causal_linear_bwd_sweep", "cwlt_causal_linear_bwd_dkdv",
+                  "cwlt_causal_linear_bwd_dq")
 
 
 def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):

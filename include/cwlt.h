@@ -47,13 +47,33 @@ int cwlt_abi_version(void);
  * state increment, a prefix pass turns increments into starting states, the scan proper starts every run from its
  * state.  cwlt_scan_segments() is the library's choice (1 once the streams fill the chip; bf16 with row strides % 8
  * == 0 only); seg_ws: cwlt_scan_seg_floats(N, H, segments, backward) floats, NULL when segments == 1.  The backward
- * calls share ONE workspace: dkdv (first) fills it, dq reads it. */
+ * calls share ONE workspace: dkdv (first) fills it, dq reads it.
+ *
+ * final_state (optional; bf16, row strides % 8 == 0, segments == 1): cwlt_scan_final_state_floats(N, H) floats that
+ * receive, per (sequence, head), the scan's state after the last token -- sum_j phi(k_j) v_j^T transposed (64 x 64 f32)
+ * followed by sum_j phi(k_j) (64 f32).  It is what cwlt_causal_linear_bwd_sweep needs to run the whole backward in one
+ * pass. */
 int cwlt_scan_segments(int N, int H, int L, int dtype);
 int64_t cwlt_scan_seg_floats(int N, int H, int segments, int backward);
+int64_t cwlt_scan_final_state_floats(int N, int H);
 int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* out, float* zinv,
                            int N, int H, int L, int head_dim,
                            int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo,
-                           float eps, int segments, float* seg_ws, int dtype, void* stream);
+                           float eps, int segments, float* seg_ws, float* final_state, int dtype, void* stream);
+
+/* The whole backward (dq, dk, dv and, optionally, their per-(sequence, head) column sums: colsum_* (N, H*64) f32, all
+ * three or none) in ONE reverse sweep: q, k, v, out, dout are each read once -- 8 streams of HBM traffic against the 12
+ * of the dkdv + dq pair below.  The dQ scan needs the state of EARLIER tokens while the sweep runs from the last token
+ * to the first: it starts from the forward's final_state and removes each chunk's contribution as it passes (f32
+ * accumulators).  bf16 with row strides % 8 == 0 only (CWLT_ERR_DTYPE / CWLT_ERR_ARG otherwise); one 8-wave workgroup
+ * per (sequence, head), so meant for launches whose N * H fills the chip -- few-stream launches use the segmented pair.
+ * Same reference call sites as above (the backward of causal_dot_product). */
+int cwlt_causal_linear_bwd_sweep(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                                 const void* dout, const float* final_state, void* dq, void* dk, void* dv,
+                                 float* colsum_q, float* colsum_k, float* colsum_v,
+                                 int N, int H, int L, int head_dim,
+                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo,
+                                 int64_t lddq, int64_t lddk, int64_t lddv, int dtype, void* stream);
 
 /* dq, dk, dv are gradients w.r.t. the RAW q, k, v (feature-map derivative applied inside);
  * out / zinv are the forward's outputs, dout the gradient w.r.t. out (row stride lddo). */

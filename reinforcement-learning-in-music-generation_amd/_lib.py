@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -43,8 +43,10 @@ _SIGNATURES = {
     "cwlt_abi_version": [],
     "cwlt_scan_segments": [_c_int, _c_int, _c_int, _c_int],
     "cwlt_scan_seg_floats": [_c_int, _c_int, _c_int, _c_int],
+    "cwlt_scan_final_state_floats": [_c_int, _c_int],
     "cwlt_causal_linear_fwd": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_int, _c_int, _c_int, _c_int,
-                               _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr, _c_int, _ptr],
+                               _c_i64, _c_i64, _c_i64, _c_i64, _c_f32, _c_int, _ptr, _ptr, _c_int, _ptr],
+    "cwlt_causal_linear_bwd_sweep": [_ptr] * 13 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
     "cwlt_causal_linear_bwd": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 8 + [_c_int, _ptr],
     "cwlt_causal_linear_bwd_dkdv": [_ptr] * 11 + [_c_int] * 4 + [_c_i64] * 7 + [_c_int, _ptr, _c_int, _ptr],
     "cwlt_causal_linear_bwd_dq": [_ptr] * 9 + [_c_int] * 4 + [_c_i64] * 6 + [_c_int, _ptr, _c_int, _ptr],
@@ -107,7 +109,8 @@ def load():
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
         fn.argtypes = argtypes
-        fn.restype = _c_i64 if name in ("cwlt_decode_workspace_floats", "cwlt_gemm_nt_tiles", "cwlt_scan_seg_floats") else _c_int
+        fn.restype = _c_i64 if name in ("cwlt_decode_workspace_floats", "cwlt_gemm_nt_tiles", "cwlt_scan_seg_floats",
+                                         "cwlt_scan_final_state_floats") else _c_int
     got = lib.cwlt_abi_version()
     if got != ABI_VERSION:
         raise ImportError("libcwlt.so ABI version %d, binding expects %d -- rebuild" % (got, ABI_VERSION))

@@ -507,9 +507,14 @@ int64_t cwlt_scan_seg_floats(int N, int H, int segments, int backward) {
     return cwlt::scan_seg_floats(N, H, segments, backward);
 }
 
+int64_t cwlt_scan_final_state_floats(int N, int H) {
+    if (N <= 0 || H <= 0) return 0;
+    return cwlt::scan_final_state_floats(N, H);
+}
+
 int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H,
                            int L, int head_dim, int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, float eps,
-                           int segments, float* seg_ws, int dtype, void* stream) {
+                           int segments, float* seg_ws, float* final_state, int dtype, void* stream) {
     using namespace cwlt;
     if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
     if (N == 0 || L == 0) return CWLT_OK;                     // empty batch / sequence: nothing to do
@@ -519,9 +524,12 @@ int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* ou
     hipStream_t st = (hipStream_t)stream;
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo) & 7) == 0;
     if (segments < 1 || (segments > 1 && (!fast || !seg_ws || segments > (L + 63) / 64))) return CWLT_ERR_ARG;
+    if (final_state && (!fast || segments != 1)) return CWLT_ERR_ARG;   // the bf16 whole-sequence kernel writes it
     if (dtype == CWLT_F32) return launch_fwd<float>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
     if (dtype == CWLT_BF16) {
-        if (fast) return launch_cla_fwd_bf16(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, segments, seg_ws, st);
+        if (fast)
+            return launch_cla_fwd_bf16(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, segments, seg_ws,
+                                       final_state, st);
         return launch_fwd<bf16_t>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
     }
     return CWLT_ERR_DTYPE;
@@ -584,6 +592,27 @@ int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const
         return launch_bwd_dq<bf16_t>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);
     }
     return CWLT_ERR_DTYPE;
+}
+
+/* the whole backward in one reverse sweep (bf16, whole sequences): every input stream is read once */
+int cwlt_causal_linear_bwd_sweep(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                                 const void* dout, const float* final_state, void* dq, void* dk, void* dv,
+                                 float* colsum_q, float* colsum_k, float* colsum_v, int N, int H, int L, int head_dim,
+                                 int64_t ldq, int64_t ldk, int64_t ldv, int64_t ldo, int64_t lddo, int64_t lddq,
+                                 int64_t lddk, int64_t lddv, int dtype, void* stream) {
+    using namespace cwlt;
+    if (N < 0 || H <= 0 || L < 0 || head_dim != D) return CWLT_ERR_ARG;
+    if (N == 0 || L == 0) return CWLT_OK;
+    if (!q || !k || !v || !out || !zinv || !dout || !final_state || !dq || !dk || !dv) return CWLT_ERR_ARG;
+    if (bad_ld(ldq, H) || bad_ld(ldk, H) || bad_ld(ldv, H) || bad_ld(ldo, H) || bad_ld(lddo, H) ||
+        bad_ld(lddq, H) || bad_ld(lddk, H) || bad_ld(lddv, H))
+        return CWLT_ERR_ARG;
+    if ((colsum_q == nullptr) != (colsum_k == nullptr) || (colsum_q == nullptr) != (colsum_v == nullptr))
+        return CWLT_ERR_ARG;
+    if (dtype != CWLT_BF16) return CWLT_ERR_DTYPE;
+    if (((ldq | ldk | ldv | ldo | lddo | lddq | lddk | lddv) & 7) != 0) return CWLT_ERR_ARG;
+    return launch_cla_bwd_sweep_bf16(q, k, v, out, zinv, dout, final_state, dq, dk, dv, colsum_q, colsum_k, colsum_v, N,
+                                     H, L, ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv, (hipStream_t)stream);
 }
 
 /* both halves of the backward: the heavier reverse scan first, the dq scan back-fills its tail */

@@ -31,6 +31,7 @@ namespace b16 {
 // instructions per element cheaper than expf -- this path is issue-bound, not HBM-bound.
 __device__ __forceinline__ float phi(float x) { return x > 0.f ? x + 1.f : __expf(x); }
 __device__ __forceinline__ float dphi(float x) { return x > 0.f ? 1.f : __expf(x); }
+constexpr int FIN_FLOATS = 65 * 64;   // per stream: the forward's final state, see cla_fwd_bf16_kernel
 // ------------------------------------------------------------------------------------------------
 // forward.  wave (wi, wj): score tile (i-half wi, j-half wj), numerator tile (i-half wi, m-half wj) and
 // half of the normaliser:  den_i = sum_j A~[i][j] * 1 + phi(q_i) . ksum,  ksum = state of the ones column.
@@ -56,7 +57,8 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
                                                            const bf16_t* __restrict__ v, bf16_t* __restrict__ o,
                                                            float* __restrict__ zinv, int H, int L, long ldq, long ldk,
                                                            long ldv, long ldo, float eps, int P, int cps,
-                                                           const float* __restrict__ pre, float* __restrict__ part) {
+                                                           const float* __restrict__ pre, float* __restrict__ part,
+                                                           float* __restrict__ fin) {
     __shared__ __attribute__((aligned(16))) bf16_t qs[C * LD];   // phi(q)  [i][e]
     __shared__ __attribute__((aligned(16))) bf16_t ks[C * LD];   // phi(k)  [j][e]
     __shared__ __attribute__((aligned(16))) bf16_t vs[C * LD];   // v       [j][m]
@@ -200,6 +202,28 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
     CLA_STORE(cend - 1);
 #undef CLA_LOAD
 #undef CLA_STORE
+    if (fin) {
+        // P == 1: the state after the last token, for the one-sweep backward (cla_bwd_sweep_bf16_kernel), as
+        // fin[stream][m][e] = S[e][m] (64 x 64 f32, row-major) followed by ksum[e] (64 f32); through the os tile so the
+        // global writes are whole rows
+        __syncthreads();
+        if (wi == 0) {
+            put_acc_T_f32(os, 32 * wj + l31, 0, S0, hf);
+            put_acc_T_f32(os, 32 * wj + l31, 32, S1, hf);
+            if (l31 == 0) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dens[0][32 * wj + acc_row(r, hf)] = Sa[r];
+            }
+        }
+        __syncthreads();
+        float* f = fin + (long)sid * FIN_FLOATS;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int row = (tid >> 4) + 16 * it, col = (tid & 15) * 4;
+            *reinterpret_cast<float4*>(f + row * 64 + col) = *reinterpret_cast<const float4*>(os + row * LDO + col);
+        }
+        if (tid < 64) f[64 * 64 + tid] = dens[0][tid];
+    }
 }
 
 // part (streams, P, 4 waves, NT tiles, 1024) f32 -> pre (streams, P, 2 column halves, NT tiles, 1024): tiles
@@ -657,7 +681,303 @@ __global__ __launch_bounds__(256, 2) void cla_bwd_dkdv_bf16_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// backward in ONE reverse sweep (whole sequences, P == 1): dQ, dK and dV from a single pass over q, k, v, out, dout.
+//   8 waves.  Waves 0-3 (the "KV" group) are the reverse scan above (dK, dV, states R).  Waves 4-7 (the "Q" group) are
+//   the dQ scan run BACKWARDS: its state S_prev (the sum over EARLIER tokens) is the forward pass's final state `fin`
+//   minus the contribution of every chunk the sweep has passed, including the current one.  The subtraction runs in the
+//   f32 accumulators with the very bf16 operands the forward added, so what is left differs from the true prefix by
+//   f32 rounding only (~2^-24 of the running total per chunk, against the 2^-9 of the bf16 operands); chunk 0 starts
+//   from an exact zero.
+//   Both groups work from the same staged LDS tiles: every input is read from HBM once (5 streams in, 3 out = 8 units
+//   against the 12 of the two-kernel schedule) and the W score tile is computed once.  Input tiles are double-buffered
+//   in LDS and two chunks are in flight in registers, so one workgroup per CU keeps as many bytes in flight as the two
+//   4-wave workgroups of the split kernels did.
+//   dden rides in the two padding columns 64 / 65 of the g tile (bf16 hi + lo), so r1 = sum_i dden_i qf_i is one more
+//   transposed-fragment MFMA per k-step instead of a per-wave hi/lo fragment build on the VALU.
+// ------------------------------------------------------------------------------------------------
+struct ChunkRegs {
+    uint4 q, k, v, g, o;
+    float z;
+};
 
+// accumulator tile (rows rr on regs, cols on lanes) times min(f, 1) of the SAME positions of tile `f_t` (phi' of the
+// staged phi values: elu'(x)+... = min(phi(x), 1)) -> x[xrow][c0 + rr], bf16, rounded once
+__device__ __forceinline__ void put_acc_T_dphi(bf16_t* x, const bf16_t* f_t, int xrow, int c0, const f32x16& acc, int hf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const uint2 fr = *reinterpret_cast<const uint2*>(f_t + xrow * LD + c0 + 8 * g + 4 * hf);
+        const float f0 = __uint_as_float(fr.x << 16), f1 = __uint_as_float(fr.x & 0xffff0000u);
+        const float f2 = __uint_as_float(fr.y << 16), f3 = __uint_as_float(fr.y & 0xffff0000u);
+        bf16x4 p;
+        p[0] = (__bf16)(acc[4 * g] * fminf(f0, 1.0f));
+        p[1] = (__bf16)(acc[4 * g + 1] * fminf(f1, 1.0f));
+        p[2] = (__bf16)(acc[4 * g + 2] * fminf(f2, 1.0f));
+        p[3] = (__bf16)(acc[4 * g + 3] * fminf(f3, 1.0f));
+        *reinterpret_cast<uint2*>(x + xrow * LD + c0 + 8 * g + 4 * hf) = __builtin_bit_cast(uint2, p);
+    }
+}
+
+__global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
+    const bf16_t* __restrict__ q, const bf16_t* __restrict__ k, const bf16_t* __restrict__ v,
+    const bf16_t* __restrict__ out, const bf16_t* __restrict__ dout, const float* __restrict__ zinv,
+    const float* __restrict__ fin, bf16_t* __restrict__ dq, bf16_t* __restrict__ dk, bf16_t* __restrict__ dv,
+    float* __restrict__ csum_q, float* __restrict__ csum_k, float* __restrict__ csum_v, int H, int L, long ldq,
+    long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv) {
+    constexpr int TILE = C * LD;
+    __shared__ __attribute__((aligned(16))) bf16_t in_[2 * 4 * TILE];   // [buffer][phi(q) | phi(k) | v | g]
+    __shared__ __attribute__((aligned(16))) bf16_t er[2 * TILE];        // [buffer] R[e][m]: the reverse state, bf16
+    __shared__ __attribute__((aligned(16))) bf16_t wt[TILE];            // masked W^T [j][i]
+    __shared__ __attribute__((aligned(16))) bf16_t at[TILE];            // masked A^T [j][i]
+    __shared__ __attribute__((aligned(16))) bf16_t ok_[TILE];           // dK tile [j][e]
+    __shared__ __attribute__((aligned(16))) bf16_t ov[TILE];            // dV tile [j][m]
+    __shared__ __attribute__((aligned(16))) bf16_t oq[TILE];            // dQ tile [i][e]
+    __shared__ float dd[2][C];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool kvg = w8 < 4;                       // KV group / Q group
+    const int w = w8 & 3, wi = w >> 1, wj = w & 1;
+    const int l31 = lane & 31, hf = lane >> 5;
+    const int sid = blockIdx.x;
+    const int n = sid / H, h = sid % H;
+    const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
+    const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
+    const bf16_t* vb = v + ((long)n * L) * ldv + h * D;
+    const bf16_t* ob = out + ((long)n * L) * ldo + h * D;
+    const bf16_t* gb = dout + ((long)n * L) * lddo + h * D;
+    const float* zb = zinv + ((long)n * L) * H + h;
+    bf16_t* dqb = dq + ((long)n * L) * lddq + h * D;
+    bf16_t* dkb = dk + ((long)n * L) * lddk + h * D;
+    bf16_t* dvb = dv + ((long)n * L) * lddv + h * D;
+
+    const int srow = tid >> 3, scol = (tid & 7) * 8;   // staging: one 16-byte slot of every stream per thread and chunk
+    const int orow = (tid & 255) >> 3;                 // output: rows orow, orow + 32 of dK and dV (KV group) / dQ (Q group)
+    const int nch = (L + C - 1) / C;
+
+    const __amdgpu_buffer_rsrc_t qr = make_rsrc(qb, (uint32_t)(((long)(L - 1) * ldq + D) * 2));
+    const __amdgpu_buffer_rsrc_t kr = make_rsrc(kb, (uint32_t)(((long)(L - 1) * ldk + D) * 2));
+    const __amdgpu_buffer_rsrc_t vr = make_rsrc(vb, (uint32_t)(((long)(L - 1) * ldv + D) * 2));
+    const __amdgpu_buffer_rsrc_t gr = make_rsrc(gb, (uint32_t)(((long)(L - 1) * lddo + D) * 2));
+    const __amdgpu_buffer_rsrc_t orr = make_rsrc(ob, (uint32_t)(((long)(L - 1) * ldo + D) * 2));
+    const __amdgpu_buffer_rsrc_t zr = make_rsrc(zb, (uint32_t)(((long)(L - 1) * H + 1) * 4));
+
+    auto load = [&](ChunkRegs& R, int c) __attribute__((always_inline)) {
+        const uint32_t row = (uint32_t)c * C + srow;
+        R.q = buf_load16(qr, (row * (uint32_t)ldq + scol) * 2);
+        R.k = buf_load16(kr, (row * (uint32_t)ldk + scol) * 2);
+        R.v = buf_load16(vr, (row * (uint32_t)ldv + scol) * 2);
+        R.g = buf_load16(gr, (row * (uint32_t)lddo + scol) * 2);
+        R.o = buf_load16(orr, (row * (uint32_t)ldo + scol) * 2);
+        R.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, (int)(row * (uint32_t)H * 4), 0, 0));
+    };
+    // registers of chunk c -> LDS buffer c & 1
+    auto stage = [&](const ChunkRegs& R, int c) __attribute__((always_inline)) {
+        bf16_t* t = in_ + (c & 1) * 4 * TILE;
+        const bool ok = c * C + srow < L;
+        float dden;
+        const uint4 gp = stage_g(R.g, R.o, R.z, dden);
+        put_row(t + 3 * TILE, srow, scol, gp);
+        if ((tid & 7) == 0) {
+            dd[c & 1][srow] = dden;
+            const __bf16 hh = (__bf16)dden;
+            const __bf16 ll = (__bf16)(dden - (float)hh);
+            const uint32_t hl = (uint32_t)__builtin_bit_cast(unsigned short, hh) |
+                                ((uint32_t)__builtin_bit_cast(unsigned short, ll) << 16);
+            put_row(t + 3 * TILE, srow, 64, make_uint4(hl, 0u, 0u, 0u));     // columns 64..71: dden hi, lo, zeros
+        }
+        put_row(t + 2 * TILE, srow, scol, R.v);
+        float x[8];
+        unpack8(R.k, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+        put_row(t + 1 * TILE, srow, scol, pack8(x));
+        unpack8(R.q, x);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+        put_row(t, srow, scol, pack8(x));
+    };
+
+    // column sums over this stream (bias gradients of the projections): KV group bs0 = dK, bs1 = dV; Q group bs0 = dQ
+    typedef float f32x8 __attribute__((ext_vector_type(8)));
+    f32x8 bs0 = 0.f, bs1 = 0.f;
+    auto widen = [](uint4 r) __attribute__((always_inline)) {
+        f32x8 x;
+        x[0] = __uint_as_float(r.x << 16); x[1] = __uint_as_float(r.x & 0xffff0000u);
+        x[2] = __uint_as_float(r.y << 16); x[3] = __uint_as_float(r.y & 0xffff0000u);
+        x[4] = __uint_as_float(r.z << 16); x[5] = __uint_as_float(r.z & 0xffff0000u);
+        x[6] = __uint_as_float(r.w << 16); x[7] = __uint_as_float(r.w & 0xffff0000u);
+        return x;
+    };
+    // finished output tiles of chunk c -> global
+    const bf16_t* t0 = kvg ? ok_ : oq;
+    bf16_t* g0 = kvg ? dkb : dqb;
+    const long l0 = kvg ? lddk : lddq;
+    auto store = [&](int c, f32x8& b0, f32x8& b1) __attribute__((always_inline)) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+            const int row = orow + 32 * it;
+            const long grow = (long)c * C + row;
+            if (grow < L) {
+                const uint4 a = *reinterpret_cast<const uint4*>(t0 + row * LD + scol);
+                b0 += widen(a);
+                *reinterpret_cast<uint4*>(g0 + grow * l0 + scol) = a;
+                if (kvg) {
+                    const uint4 b = *reinterpret_cast<const uint4*>(ov + row * LD + scol);
+                    b1 += widen(b);
+                    *reinterpret_cast<uint4*>(dvb + grow * lddv + scol) = b;
+                }
+            }
+        }
+    };
+
+    // states.  KV group: st0, st1 = RT_0, RT_1 (RT_t[m][e] = R[32wj+e][32t+m], R = sum over LATER tokens of qf g^T),
+    // st2 = RTa (rows 0 / 1 = the hi / lo parts of r1 = sum of dden_i qf_i); a bf16 copy of R lives in er[][] for the
+    // products.  Q group: st0, st1 = ST_0, ST_1 (ST_t[m][e] = S[32wj+e][32t+m]), st2 = ones row (row 0 = ksum[32wj+e]).
+    f32x16 st0 = zero16(), st1 = zero16(), st2 = zero16();
+    if (!kvg) {
+        const float* f = fin + (long)sid * FIN_FLOATS;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            st0[r] = f[acc_row(r, hf) * 64 + 32 * wj + l31];
+            st1[r] = f[(32 + acc_row(r, hf)) * 64 + 32 * wj + l31];
+        }
+        st2[0] = hf == 0 ? f[64 * 64 + 32 * wj + l31] : 0.f;
+    } else if (wi == 0) {
+        put_acc_T(er + ((nch - 1) & 1) * TILE, 32 * wj + l31, 0, st0, hf, 0, 64, 0.f);     // R = 0 behind the last chunk
+        put_acc_T(er + ((nch - 1) & 1) * TILE, 32 * wj + l31, 32, st1, hf, 0, 64, 0.f);
+    }
+    const bf16x8 ones0 = ones_if(l31 == 0);
+    bf16x8 two0 = first_if(hf == 0, 1.0f);   // picks rows 0 and 1 of an accumulator-held operand (lane-half 0)
+    two0[1] = two0[0];
+
+    auto iter = [&](int c, ChunkRegs& R) __attribute__((always_inline)) {
+        if (c < nch - 1) store(c + 1, bs0, bs1);
+        if (c >= 1) {
+            stage(R, c - 1);
+            if (c >= 3) load(R, c - 3);
+        }
+        const bf16_t* qs = in_ + (c & 1) * 4 * TILE;
+        const bf16_t* ks = qs + TILE;
+        const bf16_t* vs = qs + 2 * TILE;
+        const bf16_t* gs = qs + 3 * TILE;
+        const float dden_i = dd[c & 1][32 * wi + l31];
+        // score tiles (rows i on regs, cols j on lanes), kept where i >= j, written transposed
+        if (!(wi == 0 && wj == 1)) {
+            if (kvg) {
+                f32x16 W = prod_rows(zero16(), gs, 32 * wi + l31, vs, 32 * wj + l31, 0, 4, hf);
+                W = mfma(first_if(hf == 0, dden_i), first_if(hf == 0, 1.0f), W);     // + dden_i
+                put_acc_T(wt, 32 * wj + l31, 32 * wi, W, hf, wi == wj ? l31 : 0, 64, 0.f);
+            } else {
+                const f32x16 A = prod_rows(zero16(), qs, 32 * wi + l31, ks, 32 * wj + l31, 0, 4, hf);
+                put_acc_T(at, 32 * wj + l31, 32 * wi, A, hf, wi == wj ? l31 : 0, 64, 0.f);
+            }
+        }
+        __syncthreads();
+        if (kvg) {
+            const bf16_t* rs = er + (c & 1) * TILE;      // R behind this chunk
+            const int s0 = wi == 1 ? 2 : 0;              // contraction over i >= j: for j-half 1 only i-half 1 contributes
+            // dkf^T tile (rows e on regs, cols j on lanes) = qf^T W + R v^T + r1 (x) 1
+            f32x16 K = prod_rows(zero16(), rs, 32 * wj + l31, vs, 32 * wi + l31, 0, 4, hf);
+#pragma unroll 2
+            for (int s = s0; s < 4; ++s)
+                K = mfma(tfrag8(qs, 16 * s, 32 * wj, lane), row8(wt, 32 * wi + l31, 16 * s + 8 * hf), K);
+            {
+                bf16x8 a = first_if(hf == 0, st2[0]);      // rows 0, 1 only: the other rows of RTa are never read
+                a[1] = (__bf16)(hf == 0 ? st2[1] : 0.f);
+                K = mfma(a, two0, K);
+            }
+            put_acc_T_dphi(ok_, ks, 32 * wi + l31, 32 * wj, K, hf);
+            // dv^T tile (rows m on regs, cols j on lanes) = g^T A + R^T kf^T
+            f32x16 V = zero16();
+#pragma unroll 2
+            for (int s = 0; s < 4; ++s)
+                V = mfma(tfrag8(rs, 16 * s, 32 * wj, lane), row8(ks, 32 * wi + l31, 16 * s + 8 * hf), V);
+#pragma unroll 2
+            for (int s = s0; s < 4; ++s)
+                V = mfma(tfrag8(gs, 16 * s, 32 * wj, lane), row8(at, 32 * wi + l31, 16 * s + 8 * hf), V);
+            put_acc_T(ov, 32 * wi + l31, 32 * wj, V, hf, 0, 64, 0.f);
+            // RT_t[m][e] += sum_i g[i][32t+m] qf[i][32wj+e] ;  RTa[0 / 1][e] += sum_i dden_i (hi / lo) qf[i][32wj+e]
+#pragma unroll 2
+            for (int s = 0; s < 4; ++s) {
+                const bf16x8 bq = tfrag8(qs, 16 * s, 32 * wj, lane);
+                st0 = mfma(tfrag8(gs, 16 * s, 0, lane), bq, st0);
+                st1 = mfma(tfrag8(gs, 16 * s, 32, lane), bq, st1);
+                st2 = mfma(tfrag8(gs, 16 * s, 64, lane), bq, st2);     // g columns 64, 65 = dden hi, lo
+            }
+            if (wi == 0 && c > 0) {                      // R behind chunk c - 1, for the next iteration
+                bf16_t* rn = er + ((c - 1) & 1) * TILE;
+                put_acc_T(rn, 32 * wj + l31, 0, st0, hf, 0, 64, 0.f);
+                put_acc_T(rn, 32 * wj + l31, 32, st1, hf, 0, 64, 0.f);
+            }
+        } else {
+            // leave this chunk's own tokens out of the prefix state:  ST_t[m][e] -= sum_j v[j][32t+m] kf[j][32wj+e]
+            if (c == 0) {
+                st0 = zero16(); st1 = zero16(); st2 = zero16();
+            } else {
+#pragma unroll 2
+                for (int s = 0; s < 4; ++s) {
+                    uint4 u = __builtin_bit_cast(uint4, tfrag8(ks, 16 * s, 32 * wj, lane));
+                    u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+                    const bf16x8 nb = __builtin_bit_cast(bf16x8, u);
+                    st0 = mfma(tfrag8(vs, 16 * s, 0, lane), nb, st0);
+                    st1 = mfma(tfrag8(vs, 16 * s, 32, lane), nb, st1);
+                    st2 = mfma(ones0, nb, st2);
+                }
+            }
+            // dqf^T tile (rows e on regs, cols i on lanes) = kf^T W^T + ST^T g^T + ksum (x) dden
+            f32x16 Q = zero16();
+            const int nks = wi == 0 ? 2 : 4;    // j <= i: for i-half 0 only j-half 0 contributes
+#pragma unroll 2
+            for (int s = 0; s < nks; ++s)
+                Q = mfma(tfrag8(ks, 16 * s, 32 * wj, lane), tfrag8(wt, 16 * s, 32 * wi, lane), Q);
+            Q = prod_accA(Q, st0, st1, gs, 32 * wi + l31, hf);
+            Q = mfma(first_if(hf == 0, st2[0]), first_if(hf == 0, dden_i), Q);
+            put_acc_T_dphi(oq, qs, 32 * wi + l31, 32 * wj, Q, hf);
+        }
+        __syncthreads();
+    };
+
+    ChunkRegs RA, RB;
+    load(RA, nch - 1);
+    if (nch > 1) load(RB, nch - 2);
+    stage(RA, nch - 1);
+    if (nch > 2) load(RA, nch - 3);
+    __syncthreads();
+    for (int c = nch - 1; c >= 0; c -= 2) {
+        iter(c, RB);
+        if (c >= 1) iter(c - 1, RA);
+    }
+    store(0, bs0, bs1);
+
+    // column sums over the stream: each wave covers 16 of the rows, four waves per group
+    if (csum_q) {
+        float* scratch = reinterpret_cast<float*>(wt);     // 3 quantities x 4 waves x 64 columns; score tiles are dead
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float x = bs0[j], y = bs1[j];
+            x += __shfl_xor(x, 8, 64);
+            y += __shfl_xor(y, 8, 64);
+            x += __shfl_xor(x, 16, 64);
+            y += __shfl_xor(y, 16, 64);
+            x += __shfl_xor(x, 32, 64);
+            y += __shfl_xor(y, 32, 64);
+            if ((lane >> 3) == 0) {
+                scratch[((kvg ? 1 : 0) * 4 + w) * 64 + (lane & 7) * 8 + j] = x;
+                if (kvg) scratch[(2 * 4 + w) * 64 + (lane & 7) * 8 + j] = y;
+            }
+        }
+        __syncthreads();
+        if (tid < 192) {
+            const int a = tid >> 6, e = tid & 63;
+            const float s = (scratch[(a * 4 + 0) * 64 + e] + scratch[(a * 4 + 1) * 64 + e]) +
+                            (scratch[(a * 4 + 2) * 64 + e] + scratch[(a * 4 + 3) * 64 + e]);
+            float* dst = a == 0 ? csum_q : a == 1 ? csum_k : csum_v;
+            dst[(long)sid * D + e] = s;
+        }
+    }
+}
 
 }  // namespace b16
 
@@ -680,13 +1000,16 @@ long scan_seg_floats(int N, int H, int P, int backward) {
     return P > 1 ? (long)N * H * P * 6 * (backward ? 8 : 3) * 1024 : 0;
 }
 
+long scan_final_state_floats(int N, int H) { return (long)N * H * b16::FIN_FLOATS; }
+
 int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H, int L,
-                        long ldq, long ldk, long ldv, long ldo, float eps, int P, float* ws, hipStream_t st) {
+                        long ldq, long ldk, long ldv, long ldo, float eps, int P, float* ws, float* fin,
+                        hipStream_t st) {
     const int nch = (L + b16::C - 1) / b16::C;
     if (P <= 1) {
         hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel<false>, dim3(N * H), dim3(256), 0, st, (const bf16_t*)q,
                            (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps, 1, nch,
-                           (const float*)nullptr, (float*)nullptr);
+                           (const float*)nullptr, (float*)nullptr, fin);
         return (int)hipGetLastError();
     }
     const int cps = seg_cps(L, P);
@@ -695,13 +1018,25 @@ int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, 
     float* pre = ws + NS * P * 4 * 3 * 1024;
     hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel<true>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps, P, cps,
-                       (const float*)nullptr, part);
+                       (const float*)nullptr, part, (float*)nullptr);
     const long total = NS * 2 * 3 * 1024;
     hipLaunchKernelGGL(b16::seg_prefix_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, part, pre, total,
                        P, 3, 3);
     hipLaunchKernelGGL(b16::cla_fwd_bf16_kernel<false>, dim3(NS * P), dim3(256), 0, st, (const bf16_t*)q,
                        (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)out, zinv, H, L, ldq, ldk, ldv, ldo, eps, P, cps,
-                       (const float*)pre, (float*)nullptr);
+                       (const float*)pre, (float*)nullptr, (float*)nullptr);
+    return (int)hipGetLastError();
+}
+
+// whole-sequence backward in one sweep; `fin` = the final state launch_cla_fwd_bf16 wrote for these q, k, v
+int launch_cla_bwd_sweep_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                              const void* dout, const float* fin, void* dq, void* dk, void* dv, float* csum_q,
+                              float* csum_k, float* csum_v, int N, int H, int L, long ldq, long ldk, long ldv, long ldo,
+                              long lddo, long lddq, long lddk, long lddv, hipStream_t st) {
+    hipLaunchKernelGGL(b16::cla_bwd_sweep_bf16_kernel, dim3(N * H), dim3(512), 0, st, (const bf16_t*)q,
+                       (const bf16_t*)k, (const bf16_t*)v, (const bf16_t*)out, (const bf16_t*)dout, zinv, fin,
+                       (bf16_t*)dq, (bf16_t*)dk, (bf16_t*)dv, csum_q, csum_k, csum_v, H, L, ldq, ldk, ldv, ldo, lddo,
+                       lddq, lddk, lddv);
     return (int)hipGetLastError();
 }
 

@@ -206,8 +206,16 @@ int launch_colsum_finalize_multi(const float* part, float* out, long out_stride,
 // P = segments per stream (scan_segments: 1 unless N * H is far below the CU count), ws = scan_seg_floats(...) floats.
 int scan_segments(int N, int H, int L);
 long scan_seg_floats(int N, int H, int P, int backward);
+// fin (optional, P == 1): scan_final_state_floats(N, H) floats, the state after the last token -- what the one-sweep
+// backward (launch_cla_bwd_sweep_bf16) starts its dQ scan from.
+long scan_final_state_floats(int N, int H);
 int launch_cla_fwd_bf16(const void* q, const void* k, const void* v, void* out, float* zinv, int N, int H, int L,
-                        long ldq, long ldk, long ldv, long ldo, float eps, int P, float* ws, hipStream_t st);
+                        long ldq, long ldk, long ldv, long ldo, float eps, int P, float* ws, float* fin,
+                        hipStream_t st);
+int launch_cla_bwd_sweep_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
+                              const void* dout, const float* fin, void* dq, void* dk, void* dv, float* csum_q,
+                              float* csum_k, float* csum_v, int N, int H, int L, long ldq, long ldk, long ldv, long ldo,
+                              long lddo, long lddq, long lddk, long lddv, hipStream_t st);
 int launch_cla_bwd_dq_bf16(const void* q, const void* k, const void* v, const void* out, const float* zinv,
                            const void* dout, const float* dden, void* dq, float* csum, int N, int H, int L, long ldq,
                            long ldk, long ldv, long ldo, long lddo, long lddq, int P, float* ws, hipStream_t st);

@@ -56,7 +56,10 @@ class _EncoderLayerFn(torch.autograd.Function):
 
         qkv = torch.addmm(bqkv, x2, wqkv.t())                              # (R, 3D)  MFMA
         qkv5 = qkv.view(N, L, 3, H, D // H)
-        _, _, _, a, zinv = ops.cla_fwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2])
+        # with a backward to follow, the bf16 scan also hands over its final state: the backward is then one sweep
+        _, _, _, a, zinv, fin = ops.cla_fwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2],
+                                            final_state=any(ctx.needs_input_grad))
+        ctx.fin = fin
         a2 = a.view(R, D)
         o = torch.addmm(bo_a, a2, wo_a.t())                                # MFMA
         s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
@@ -121,7 +124,8 @@ class _EncoderLayerFn(torch.autograd.Function):
         dwo = wgrad(do, a.view(R, D))
         qkv5 = qkv.view(N, L, 3, H, D // H)
         dqkv, dbqkv = ops.cla_bwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2], a, zinv, da.view(N, L, H, D // H),
-                                  want_colsum=True)
+                                  want_colsum=True, final_state=ctx.fin)
+        ctx.fin = None
         dqkv2 = dqkv.view(R, 3 * D)
         dx = ds1.addmm_(dqkv2, wqkv)                                       # residual + projection gradient, in place
                                                                            # (NN is the faster form for this shape)

@@ -396,8 +396,14 @@ def _seg_ws(N, H, P, backward, device):
     return torch.empty(n, dtype=torch.float32, device=device)
 
 
-def cla_fwd(q, k, v, eps=CLA_EPS):
-    """q, k, v: (N, L, H, 64) views (row-strided ok) -> out (N, L, H, 64) dense, zinv (N, L, H) f32."""
+# One-sweep backward of the bf16 scan (cwlt_causal_linear_bwd_sweep); CWLT_SCAN_SWEEP=0 keeps the dkdv + dq pair.
+SCAN_SWEEP = os.environ.get("CWLT_SCAN_SWEEP", "1") != "0"
+
+
+def cla_fwd(q, k, v, eps=CLA_EPS, final_state=False):
+    """q, k, v: (N, L, H, 64) views (row-strided ok) -> out (N, L, H, 64) dense, zinv (N, L, H) f32
+    [, fin: the scan's final state for `cla_bwd(final_state=fin)`, or None where the one-sweep backward does not apply
+    (f32, odd row strides, segmented few-stream launches) -- only with final_state=True]."""
     lib = _lib.load()
     N, L, H, D = q.shape
     if k.shape != q.shape or v.shape != q.shape:
@@ -409,16 +415,24 @@ def cla_fwd(q, k, v, eps=CLA_EPS):
     v, ldv = _as_rows(v)
     out = torch.empty((N, L, H, D), dtype=q.dtype, device=q.device)
     zinv = torch.empty((N, L, H), dtype=torch.float32, device=q.device)
-    P = scan_segments(N, H, L, q.dtype, all(x % 8 == 0 for x in (ldq, ldk, ldv)))
+    fast = q.dtype == torch.bfloat16 and all(x % 8 == 0 for x in (ldq, ldk, ldv))
+    P = scan_segments(N, H, L, q.dtype, fast)
     ws = _seg_ws(N, H, P, False, q.device)
+    fin = None
+    if final_state and SCAN_SWEEP and fast and P == 1 and N * L > 0:
+        fin = torch.empty(int(lib.cwlt_scan_final_state_floats(N, H)), dtype=torch.float32, device=q.device)
     _call("cwlt_causal_linear_fwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.dev(out), _lib.dev(zinv),
-        N, H, L, D, ldq, ldk, ldv, H * D, float(eps), P, _lib.opt(ws), _lib.dtype_code(q.dtype), _lib.stream_ptr())
+        N, H, L, D, ldq, ldk, ldv, H * D, float(eps), P, _lib.opt(ws), _lib.opt(fin), _lib.dtype_code(q.dtype),
+        _lib.stream_ptr())
+    if final_state:
+        return q, k, v, out, zinv, fin
     return q, k, v, out, zinv
 
 
-def cla_bwd(q, k, v, out, zinv, dout, want_colsum=False):
+def cla_bwd(q, k, v, out, zinv, dout, want_colsum=False, final_state=None):
     """-> dqkv (N, L, 3, H, 64): dq | dk | dv side by side (= gradient of a fused QKV projection)
-    [, dbias (3*H*64) f32 = its column sums, fused into the kernels on the bf16 path]."""
+    [, dbias (3*H*64) f32 = its column sums, fused into the kernels on the bf16 path].
+    final_state: what `cla_fwd(final_state=True)` returned for these q, k, v -- the backward then runs as one sweep."""
     lib = _lib.load()
     N, L, H, D = q.shape
     dout, lddo = _as_rows(dout)
@@ -431,6 +445,17 @@ def cla_bwd(q, k, v, out, zinv, dout, want_colsum=False):
     code, st = _lib.dtype_code(q.dtype), _lib.stream_ptr()
     fast = q.dtype == torch.bfloat16 and all(x % 8 == 0 for x in (ldq, ldk, ldv, lddo))
     fused = want_colsum and fast
+    if final_state is not None:
+        if not fast:
+            raise ValueError("the one-sweep backward needs bf16 tensors with row strides that are multiples of 8")
+        cs = torch.empty((3, N, H * D), dtype=torch.float32, device=q.device) if want_colsum else None
+        _call("cwlt_causal_linear_bwd_sweep", *common, _lib.dev(final_state), _lib.dev(dqkv[:, :, 0]),
+              _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]), *([_lib.dev(cs[i]) for i in range(3)] if want_colsum
+                                                                  else [None] * 3),
+              N, H, L, D, ldq, ldk, ldv, H * D, lddo, ld, ld, ld, code, st)
+        if not want_colsum:
+            return dqkv
+        return dqkv, (cs.sum(1).reshape(3 * H * D) if N > 1 else cs.reshape(3 * H * D))
     P = scan_segments(N, H, L, q.dtype, fast)
     ws = _seg_ws(N, H, P, True, q.device)          # shared by the two calls: dkdv fills it, dq reads it
     cs = torch.empty((3, N * P, H * D), dtype=torch.float32, device=q.device) if fused else None
@@ -459,14 +484,15 @@ class CausalLinearAttentionFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, q, k, v, eps=CLA_EPS):
-        q, k, v, out, zinv = cla_fwd(q, k, v, eps)
+        q, k, v, out, zinv, fin = cla_fwd(q, k, v, eps, final_state=True)
         ctx.save_for_backward(q, k, v, out, zinv)
+        ctx.fin = fin
         return out
 
     @staticmethod
     def backward(ctx, dout):
         q, k, v, out, zinv = ctx.saved_tensors
-        dqkv = cla_bwd(q, k, v, out, zinv, dout)
+        dqkv = cla_bwd(q, k, v, out, zinv, dout, final_state=ctx.fin)
         return dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], None
 
 

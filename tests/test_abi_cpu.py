@@ -44,9 +44,9 @@ def test_argument_validation_without_gpu(built):
     """Entry points refuse bad arguments before touching the device."""
     lib = built.load()
     null = ctypes.c_void_p(0)
-    assert lib.cwlt_causal_linear_fwd(null, null, null, null, null, 1, 8, 16, 64, 512, 512, 512, 512, 1e-6, 1, null, 0, null) == 1001
+    assert lib.cwlt_causal_linear_fwd(null, null, null, null, null, 1, 8, 16, 64, 512, 512, 512, 512, 1e-6, 1, null, null, 0, null) == 1001
     buf = ctypes.c_void_p(16)   # non-null dummy; rejected on head_dim before any launch
-    assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 1, null, 0, null) == 1001
+    assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, 16, 32, 512, 512, 512, 512, 1e-6, 1, null, null, 0, null) == 1001
     assert lib.cwlt_add_dropout_layernorm_fwd(null, null, null, null, null, null, null, null, 4, 512, 1e-5, 0.0, 0, null, 0, null) == 1001
     assert lib.cwlt_ln_blocks(65536) == 1024 and lib.cwlt_ln_blocks(1) == 1
     # weight-gradient split counts: ~one workgroup per CU in multiples of 8 at training sizes, slices of >= 256 token

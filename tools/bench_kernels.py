@@ -33,12 +33,17 @@ def main():
         qkv = torch.randn(B, T, 3, H, D, device=dev).to(dt)
         dout = torch.randn(B, T, H, D, device=dev).to(dt)
         q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-        _, _, _, out, zinv = ops.cla_fwd(q, k, v)
+        _, _, _, out, zinv, fin = ops.cla_fwd(q, k, v, final_state=True)
         R = B * T
         t = timeit(lambda: ops.cla_fwd(q, k, v))
         print("%-8s cla_fwd   %8.1f us  %7.1f GB/s (algorithmic)" % (dt, t * 1e3, R * 4 * 512 * s / t / 1e6))
         t = timeit(lambda: ops.cla_bwd(q, k, v, out, zinv, dout))
-        print("%-8s cla_bwd   %8.1f us  %7.1f GB/s (algorithmic, 7 streams)" % (dt, t * 1e3, R * 7 * 512 * s / t / 1e6))
+        print("%-8s cla_bwd   %8.1f us  %7.1f GB/s (algorithmic, 7 streams; dkdv + dq pair)" % (dt, t * 1e3, R * 7 * 512 * s / t / 1e6))
+        if fin is not None:
+            t = timeit(lambda: ops.cla_fwd(q, k, v, final_state=True))
+            print("%-8s cla_fwd   %8.1f us  with the final-state hand-over" % (dt, t * 1e3))
+            t = timeit(lambda: ops.cla_bwd(q, k, v, out, zinv, dout, want_colsum=True, final_state=fin))
+            print("%-8s cla_bwd   %8.1f us  %7.1f GB/s (algorithmic, 7 streams; one sweep)" % (dt, t * 1e3, R * 7 * 512 * s / t / 1e6))
 
 
 def bench_wgrad():

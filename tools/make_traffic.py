@@ -14,7 +14,7 @@ import os
 import sys
 from collections import defaultdict
 
-ENTRY = [("cla_fwd_bf16_kernel", "cwlt_causal_linear_fwd"), ("cla_bwd_dq_bf16_kernel", "cwlt_causal_linear_bwd_dq"),
+ENTRY = [("cla_fwd_bf16_kernel", "cwlt_causal_linear_fwd"), ("cla_bwd_sweep_bf16_kernel", "cwlt_causal_linear_bwd_sweep"), ("cla_bwd_dq_bf16_kernel", "cwlt_causal_linear_bwd_dq"),
          ("cla_bwd_dkdv_bf16_kernel", "cwlt_causal_linear_bwd_dkdv"), ("add_dropout_ln_fwd_kernel", "cwlt_add_dropout_layernorm_fwd"),
          ("add_dropout_ln_bwd_kernel", "cwlt_add_dropout_layernorm_bwd"), ("bias_gelu_dropout_fwd_kernel", "cwlt_bias_gelu_dropout_fwd"),
          ("bias_gelu_dropout_bwd_kernel", "cwlt_bias_gelu_dropout_bwd"), ("wgrad_kernel", "cwlt_wgrad_bf16"),
@@ -50,7 +50,9 @@ def main():
         if fn[ent] and wn.get(ent):
             out[ent] = int(round((2.0 * ft[ent] / fn[ent] + wt[ent] / wn[ent]) * 1024))
     # the attention backward as bench.py prices it: ONE unit per attention call = its two launches together
-    if "cwlt_causal_linear_bwd_dkdv" in out and "cwlt_causal_linear_bwd_dq" in out:
+    if "cwlt_causal_linear_bwd_sweep" in out:
+        out["cwlt_causal_linear_bwd"] = out["cwlt_causal_linear_bwd_sweep"]
+    elif "cwlt_causal_linear_bwd_dkdv" in out and "cwlt_causal_linear_bwd_dq" in out:
         out["cwlt_causal_linear_bwd"] = out["cwlt_causal_linear_bwd_dkdv"] + out["cwlt_causal_linear_bwd_dq"]
     meta = {"batch": int(sys.argv[3]) if len(sys.argv) > 3 else 512, "seq": 1024, "dtype": "bf16",
             "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on bench.py --steps 2 --warmup 1; "

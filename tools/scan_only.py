@@ -1,4 +1,4 @@
-"""Run only the bf16 scan kernels (forward, dQ, dK/dV) a few times at the bench shape -- target for rocprofv3
+"""Run only the bf16 scan kernels (forward, dQ, dK/dV, one-sweep backward) a few times at the bench shape -- target for rocprofv3
 --pmc passes.  usage: python tools/scan_only.py [B] [T] [reps]"""
 import os
 import sys
@@ -17,7 +17,9 @@ qkv = torch.randn(B, T, 3, 8, 64, device=dev).bfloat16()
 dout = torch.randn(B, T, 8, 64, device=dev).bfloat16()
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
 for _ in range(reps):
-    _, _, _, out, zinv = ops.cla_fwd(q, k, v)
-    ops.cla_bwd(q, k, v, out, zinv, dout, want_colsum=True)
+    _, _, _, out, zinv, fin = ops.cla_fwd(q, k, v, final_state=True)
+    ops.cla_bwd(q, k, v, out, zinv, dout, want_colsum=True)                       # the dkdv + dq pair
+    if fin is not None:
+        ops.cla_bwd(q, k, v, out, zinv, dout, want_colsum=True, final_state=fin)  # one sweep
 torch.cuda.synchronize()
 print("done")
