@@ -46,7 +46,10 @@ SCAN_BWD_PARTS = ("cwlt_causal_linear_bwd", "cwlt_causal_linear_bwd_sweep", "cwl
 def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
     """Algorithmic HBM bytes of ONE launch of a libcwlt entry point at this workload.
     s = bytes per activation element.  The attention backward is priced as ONE unit whatever its launch count:
-    7 * D * s per token (Q, K, V, dOut read; dQ, dK, dV written) -- re-reads by a second kernel are waste, not work."""
+    7 * D * s per token (Q, K, V, dOut read; dQ, dK, dV written) -- re-reads by a second kernel, and the one-sweep
+    kernel's read of `out` (needed only for dden), are waste, not work.  Likewise the forward activation is priced at
+    2 * F * s although, with the fused FFN backward, it also writes gd (a third stream, the backward's activation
+    derivative): `traffic_GB/s` next to `achieved` shows what the kernel really moves."""
     R = B * T
     return {
         "cwlt_causal_linear_fwd": R * (4 * D * s + H * 4),
@@ -173,6 +176,10 @@ def report(args, kt, B, T, s, world, ms_per_step, tokens_per_s, final_loss, repl
                 traffic = tj.get("per_launch_bytes", {})
         for _, e in cands:
             e["traffic"] = traffic.get(e["kernel"])
+            if e["traffic"] and e["bound"] == "hbm":
+                # bytes the counters saw per launch / this run's launch time, and how far they exceed the algorithmic ones
+                e["traffic_GB/s"] = round(e["traffic"] / (e["avg_launch_ms"] * 1e-3) / 1e9, 1)
+                e["traffic_over_algorithmic"] = round(e["traffic"] / e["algorithmic_bytes_per_launch"], 3)
         cands.sort(key=lambda t: -t[0])
         # `roofline`: the libcwlt entry point with the largest total time in the step, whatever bounds it;
         # `roofline_hbm` / `roofline_mfma`: the largest one of each kind

@@ -701,8 +701,11 @@ struct ChunkRegs {
     float z;
 };
 
+// min(f, 1) for f >= 0 (f = a staged phi value): one v_med3_f32, no NaN canonicalisation in front
+__device__ __forceinline__ float min1(float f) { return __builtin_amdgcn_fmed3f(f, 0.0f, 1.0f); }
+
 // accumulator tile (rows rr on regs, cols on lanes) times min(f, 1) of the SAME positions of tile `f_t` (phi' of the
-// staged phi values: elu'(x)+... = min(phi(x), 1)) -> x[xrow][c0 + rr], bf16, rounded once
+// staged phi values: phi' = min(phi, 1)) -> x[xrow][c0 + rr], bf16, rounded once
 __device__ __forceinline__ void put_acc_T_dphi(bf16_t* x, const bf16_t* f_t, int xrow, int c0, const f32x16& acc, int hf) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -710,12 +713,44 @@ __device__ __forceinline__ void put_acc_T_dphi(bf16_t* x, const bf16_t* f_t, int
         const float f0 = __uint_as_float(fr.x << 16), f1 = __uint_as_float(fr.x & 0xffff0000u);
         const float f2 = __uint_as_float(fr.y << 16), f3 = __uint_as_float(fr.y & 0xffff0000u);
         bf16x4 p;
-        p[0] = (__bf16)(acc[4 * g] * fminf(f0, 1.0f));
-        p[1] = (__bf16)(acc[4 * g + 1] * fminf(f1, 1.0f));
-        p[2] = (__bf16)(acc[4 * g + 2] * fminf(f2, 1.0f));
-        p[3] = (__bf16)(acc[4 * g + 3] * fminf(f3, 1.0f));
+        p[0] = (__bf16)(acc[4 * g] * min1(f0));
+        p[1] = (__bf16)(acc[4 * g + 1] * min1(f1));
+        p[2] = (__bf16)(acc[4 * g + 2] * min1(f2));
+        p[3] = (__bf16)(acc[4 * g + 3] * min1(f3));
         *reinterpret_cast<uint2*>(x + xrow * LD + c0 + 8 * g + 4 * hf) = __builtin_bit_cast(uint2, p);
     }
+}
+// accumulator tile -> x[xrow][c0 + rr], bf16, all of it (no mask, nothing added)
+__device__ __forceinline__ void put_acc_T_all(bf16_t* x, int xrow, int c0, const f32x16& acc, int hf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 p;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = (__bf16)acc[4 * g + u];
+        *reinterpret_cast<uint2*>(x + xrow * LD + c0 + 8 * g + 4 * hf) = __builtin_bit_cast(uint2, p);
+    }
+}
+// accumulator tile -> x[xrow][c0 + rr], bf16, kept where rr >= lo (the diagonal score tiles)
+__device__ __forceinline__ void put_acc_T_ge(bf16_t* x, int xrow, int c0, const f32x16& acc, int hf, int lo) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        bf16x4 p;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = (__bf16)(8 * g + 4 * hf + u >= lo ? acc[4 * g + u] : 0.f);
+        *reinterpret_cast<uint2*>(x + xrow * LD + c0 + 8 * g + 4 * hf) = __builtin_bit_cast(uint2, p);
+    }
+}
+// sum over four k-steps of a_t[arow][k] * b_t[brow][k], chain started from the MFMA's zero C operand
+__device__ __forceinline__ f32x16 prod_rows4(const bf16_t* a_t, int arow, const bf16_t* b_t, int brow, int hf) {
+    f32x16 acc = mfma(row8(a_t, arow, 8 * hf), row8(b_t, brow, 8 * hf), zero16());
+#pragma unroll
+    for (int s = 1; s < 4; ++s) acc = mfma(row8(a_t, arow, 16 * s + 8 * hf), row8(b_t, brow, 16 * s + 8 * hf), acc);
+    return acc;
+}
+__device__ __forceinline__ bf16x8 negate8(bf16x8 x) {
+    uint4 u = __builtin_bit_cast(uint4, x);
+    u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
+    return __builtin_bit_cast(bf16x8, u);
 }
 
 __global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
@@ -726,13 +761,16 @@ __global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
     long ldk, long ldv, long ldo, long lddo, long lddq, long lddk, long lddv) {
     constexpr int TILE = C * LD;
     __shared__ __attribute__((aligned(16))) bf16_t in_[2 * 4 * TILE];   // [buffer][phi(q) | phi(k) | v | g]
-    __shared__ __attribute__((aligned(16))) bf16_t er[2 * TILE];        // [buffer] R[e][m]: the reverse state, bf16
+    __shared__ __attribute__((aligned(16))) bf16_t er[2 * TILE];        // [buffer] R[e][m]: reverse state behind a chunk
+    __shared__ __attribute__((aligned(16))) bf16_t es[TILE];            // S[e][m]: forward state in front of the chunk
     __shared__ __attribute__((aligned(16))) bf16_t wt[TILE];            // masked W^T [j][i]
     __shared__ __attribute__((aligned(16))) bf16_t at[TILE];            // masked A^T [j][i]
     __shared__ __attribute__((aligned(16))) bf16_t ok_[TILE];           // dK tile [j][e]
     __shared__ __attribute__((aligned(16))) bf16_t ov[TILE];            // dV tile [j][m]
     __shared__ __attribute__((aligned(16))) bf16_t oq[TILE];            // dQ tile [i][e]
     __shared__ float dd[2][C];
+    __shared__ float r1s[2][C];                                         // r1[e] behind a chunk (see er)
+    __shared__ float ksm[C];                                            // ksum[e] in front of the chunk (see es)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w8 = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -771,15 +809,14 @@ __global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
         R.o = buf_load16(orr, (row * (uint32_t)ldo + scol) * 2);
         R.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(zr, (int)(row * (uint32_t)H * 4), 0, 0));
     };
-    // registers of chunk c -> LDS buffer c & 1
-    auto stage = [&](const ChunkRegs& R, int c) __attribute__((always_inline)) {
-        bf16_t* t = in_ + (c & 1) * 4 * TILE;
-        const bool ok = c * C + srow < L;
+    // registers of chunk c -> LDS buffer b
+    auto stage = [&](const ChunkRegs& R, int c, int b) __attribute__((always_inline)) {
+        bf16_t* t = in_ + b * 4 * TILE;
         float dden;
         const uint4 gp = stage_g(R.g, R.o, R.z, dden);
         put_row(t + 3 * TILE, srow, scol, gp);
         if ((tid & 7) == 0) {
-            dd[c & 1][srow] = dden;
+            dd[b][srow] = dden;
             const __bf16 hh = (__bf16)dden;
             const __bf16 ll = (__bf16)(dden - (float)hh);
             const uint32_t hl = (uint32_t)__builtin_bit_cast(unsigned short, hh) |
@@ -787,15 +824,20 @@ __global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
             put_row(t + 3 * TILE, srow, 64, make_uint4(hl, 0u, 0u, 0u));     // columns 64..71: dden hi, lo, zeros
         }
         put_row(t + 2 * TILE, srow, scol, R.v);
-        float x[8];
+        float x[8], y[8];
         unpack8(R.k, x);
+        unpack8(R.q, y);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
+        for (int j = 0; j < 8; ++j) {
+            x[j] = phi(x[j]);
+            y[j] = phi(y[j]);
+        }
+        if ((c + 1) * C > L && c * C + srow >= L) {      // rows past the end of a ragged last chunk: phi(0) = 1 is not 0
+#pragma unroll
+            for (int j = 0; j < 8; ++j) x[j] = y[j] = 0.f;
+        }
         put_row(t + 1 * TILE, srow, scol, pack8(x));
-        unpack8(R.q, x);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) x[j] = ok ? phi(x[j]) : 0.f;
-        put_row(t, srow, scol, pack8(x));
+        put_row(t, srow, scol, pack8(y));
     };
 
     // column sums over this stream (bias gradients of the projections): KV group bs0 = dK, bs1 = dV; Q group bs0 = dQ
@@ -831,108 +873,120 @@ __global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
         }
     };
 
-    // states.  KV group: st0, st1 = RT_0, RT_1 (RT_t[m][e] = R[32wj+e][32t+m], R = sum over LATER tokens of qf g^T),
-    // st2 = RTa (rows 0 / 1 = the hi / lo parts of r1 = sum of dden_i qf_i); a bf16 copy of R lives in er[][] for the
-    // products.  Q group: st0, st1 = ST_0, ST_1 (ST_t[m][e] = S[32wj+e][32t+m]), st2 = ones row (row 0 = ksum[32wj+e]).
-    f32x16 st0 = zero16(), st1 = zero16(), st2 = zero16();
+    // running states, one 32 x 32 tile per wave (wi = m-half, wj = e-half), f32 for the whole sequence:
+    //   KV group: st[m][e] = R[32wj+e][32wi+m], R = sum over LATER tokens of qf g^T; waves wi == 0 also sa rows 0 / 1 =
+    //             the hi / lo parts of r1 = sum of dden_i qf_i.
+    //   Q group:  st[m][e] = S[32wj+e][32wi+m], S = sum over EARLIER tokens of kf v^T; waves wi == 0 also sa row 0 = ksum.
+    // The products read them from LDS (er / es, bf16; r1s / ksm), where every wave finds all four tiles.
+    f32x16 st = zero16(), sa = zero16();
     if (!kvg) {
         const float* f = fin + (long)sid * FIN_FLOATS;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            st0[r] = f[acc_row(r, hf) * 64 + 32 * wj + l31];
-            st1[r] = f[(32 + acc_row(r, hf)) * 64 + 32 * wj + l31];
-        }
-        st2[0] = hf == 0 ? f[64 * 64 + 32 * wj + l31] : 0.f;
-    } else if (wi == 0) {
-        put_acc_T(er + ((nch - 1) & 1) * TILE, 32 * wj + l31, 0, st0, hf, 0, 64, 0.f);     // R = 0 behind the last chunk
-        put_acc_T(er + ((nch - 1) & 1) * TILE, 32 * wj + l31, 32, st1, hf, 0, 64, 0.f);
+        for (int r = 0; r < 16; ++r) st[r] = f[(32 * wi + acc_row(r, hf)) * 64 + 32 * wj + l31];
+        if (wi == 0) sa[0] = hf == 0 ? f[64 * 64 + 32 * wj + l31] : 0.f;
+    } else {
+        put_acc_T_all(er, 32 * wj + l31, 32 * wi, st, hf);     // R = 0 behind the last chunk
+        if (wi == 0 && hf == 0) r1s[0][32 * wj + l31] = 0.f;
     }
     const bf16x8 ones0 = ones_if(l31 == 0);
-    bf16x8 two0 = first_if(hf == 0, 1.0f);   // picks rows 0 and 1 of an accumulator-held operand (lane-half 0)
-    two0[1] = two0[0];
+    const bf16x8 one0 = first_if(hf == 0, 1.0f);
 
-    auto iter = [&](int c, ChunkRegs& R) __attribute__((always_inline)) {
+    // b: the buffer chunk c was staged in = the parity of its distance from the last chunk (a literal at both call sites)
+    auto iter = [&](int c, ChunkRegs& R, const int b) __attribute__((always_inline)) {
         if (c < nch - 1) store(c + 1, bs0, bs1);
         if (c >= 1) {
-            stage(R, c - 1);
+            stage(R, c - 1, 1 - b);
             if (c >= 3) load(R, c - 3);
         }
-        const bf16_t* qs = in_ + (c & 1) * 4 * TILE;
+        const bf16_t* qs = in_ + b * 4 * TILE;
         const bf16_t* ks = qs + TILE;
         const bf16_t* vs = qs + 2 * TILE;
         const bf16_t* gs = qs + 3 * TILE;
-        const float dden_i = dd[c & 1][32 * wi + l31];
-        // score tiles (rows i on regs, cols j on lanes), kept where i >= j, written transposed
-        if (!(wi == 0 && wj == 1)) {
-            if (kvg) {
-                f32x16 W = prod_rows(zero16(), gs, 32 * wi + l31, vs, 32 * wj + l31, 0, 4, hf);
-                W = mfma(first_if(hf == 0, dden_i), first_if(hf == 0, 1.0f), W);     // + dden_i
-                put_acc_T(wt, 32 * wj + l31, 32 * wi, W, hf, wi == wj ? l31 : 0, 64, 0.f);
-            } else {
-                const f32x16 A = prod_rows(zero16(), qs, 32 * wi + l31, ks, 32 * wj + l31, 0, 4, hf);
-                put_acc_T(at, 32 * wj + l31, 32 * wi, A, hf, wi == wj ? l31 : 0, 64, 0.f);
-            }
-        }
-        __syncthreads();
+        const float dden_i = dd[b][32 * wi + l31];
+        __builtin_amdgcn_sched_barrier(0);      // keep the fragment reads of a product next to it: registers are short
+        // ---- phase 1: score tiles (rows i on regs, cols j on lanes; kept where i >= j, written transposed) and states
         if (kvg) {
-            const bf16_t* rs = er + (c & 1) * TILE;      // R behind this chunk
-            const int s0 = wi == 1 ? 2 : 0;              // contraction over i >= j: for j-half 1 only i-half 1 contributes
-            // dkf^T tile (rows e on regs, cols j on lanes) = qf^T W + R v^T + r1 (x) 1
-            f32x16 K = prod_rows(zero16(), rs, 32 * wj + l31, vs, 32 * wi + l31, 0, 4, hf);
-#pragma unroll 2
-            for (int s = s0; s < 4; ++s)
-                K = mfma(tfrag8(qs, 16 * s, 32 * wj, lane), row8(wt, 32 * wi + l31, 16 * s + 8 * hf), K);
-            {
-                bf16x8 a = first_if(hf == 0, st2[0]);      // rows 0, 1 only: the other rows of RTa are never read
-                a[1] = (__bf16)(hf == 0 ? st2[1] : 0.f);
-                K = mfma(a, two0, K);
+            if (!(wi == 0 && wj == 1)) {
+                f32x16 W = prod_rows4(gs, 32 * wi + l31, vs, 32 * wj + l31, hf);
+                W = mfma(first_if(hf == 0, dden_i), one0, W);                        // + dden_i
+                if (wi == wj) put_acc_T_ge(wt, 32 * wj + l31, 32 * wi, W, hf, l31);
+                else put_acc_T_all(wt, 32 * wj + l31, 32 * wi, W, hf);
             }
-            put_acc_T_dphi(ok_, ks, 32 * wi + l31, 32 * wj, K, hf);
-            // dv^T tile (rows m on regs, cols j on lanes) = g^T A + R^T kf^T
-            f32x16 V = zero16();
-#pragma unroll 2
-            for (int s = 0; s < 4; ++s)
-                V = mfma(tfrag8(rs, 16 * s, 32 * wj, lane), row8(ks, 32 * wi + l31, 16 * s + 8 * hf), V);
-#pragma unroll 2
-            for (int s = s0; s < 4; ++s)
-                V = mfma(tfrag8(gs, 16 * s, 32 * wj, lane), row8(at, 32 * wi + l31, 16 * s + 8 * hf), V);
-            put_acc_T(ov, 32 * wi + l31, 32 * wj, V, hf, 0, 64, 0.f);
-            // RT_t[m][e] += sum_i g[i][32t+m] qf[i][32wj+e] ;  RTa[0 / 1][e] += sum_i dden_i (hi / lo) qf[i][32wj+e]
-#pragma unroll 2
+            __builtin_amdgcn_sched_barrier(0);
+            // st[m][e] += sum_i g[i][32wi+m] qf[i][32wj+e] ;  sa[0 / 1][e] += sum_i dden_i (hi / lo) qf[i][32wj+e]
+#pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const bf16x8 bq = tfrag8(qs, 16 * s, 32 * wj, lane);
-                st0 = mfma(tfrag8(gs, 16 * s, 0, lane), bq, st0);
-                st1 = mfma(tfrag8(gs, 16 * s, 32, lane), bq, st1);
-                st2 = mfma(tfrag8(gs, 16 * s, 64, lane), bq, st2);     // g columns 64, 65 = dden hi, lo
+                st = mfma(tfrag8(gs, 16 * s, 32 * wi, lane), bq, st);
+                if (wi == 0) sa = mfma(tfrag8(gs, 16 * s, 64, lane), bq, sa);        // g columns 64, 65 = dden hi, lo
             }
-            if (wi == 0 && c > 0) {                      // R behind chunk c - 1, for the next iteration
-                bf16_t* rn = er + ((c - 1) & 1) * TILE;
-                put_acc_T(rn, 32 * wj + l31, 0, st0, hf, 0, 64, 0.f);
-                put_acc_T(rn, 32 * wj + l31, 32, st1, hf, 0, 64, 0.f);
+            if (c > 0) {                                  // R and r1 behind chunk c - 1, for the next iteration
+                put_acc_T_all(er + (1 - b) * TILE, 32 * wj + l31, 32 * wi, st, hf);
+                if (wi == 0 && hf == 0) r1s[1 - b][32 * wj + l31] = sa[0] + sa[1];
             }
         } else {
-            // leave this chunk's own tokens out of the prefix state:  ST_t[m][e] -= sum_j v[j][32t+m] kf[j][32wj+e]
+            if (!(wi == 0 && wj == 1)) {
+                const f32x16 A = prod_rows4(qs, 32 * wi + l31, ks, 32 * wj + l31, hf);
+                if (wi == wj) put_acc_T_ge(at, 32 * wj + l31, 32 * wi, A, hf, l31);
+                else put_acc_T_all(at, 32 * wj + l31, 32 * wi, A, hf);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // leave this chunk's own tokens out of the prefix state:  st[m][e] -= sum_j v[j][32wi+m] kf[j][32wj+e]
             if (c == 0) {
-                st0 = zero16(); st1 = zero16(); st2 = zero16();
+                st = zero16();
+                sa = zero16();
             } else {
-#pragma unroll 2
+#pragma unroll
                 for (int s = 0; s < 4; ++s) {
-                    uint4 u = __builtin_bit_cast(uint4, tfrag8(ks, 16 * s, 32 * wj, lane));
-                    u.x ^= 0x80008000u; u.y ^= 0x80008000u; u.z ^= 0x80008000u; u.w ^= 0x80008000u;
-                    const bf16x8 nb = __builtin_bit_cast(bf16x8, u);
-                    st0 = mfma(tfrag8(vs, 16 * s, 0, lane), nb, st0);
-                    st1 = mfma(tfrag8(vs, 16 * s, 32, lane), nb, st1);
-                    st2 = mfma(ones0, nb, st2);
+                    const bf16x8 nb = negate8(tfrag8(ks, 16 * s, 32 * wj, lane));
+                    st = mfma(tfrag8(vs, 16 * s, 32 * wi, lane), nb, st);
+                    if (wi == 0) sa = mfma(ones0, nb, sa);
                 }
             }
-            // dqf^T tile (rows e on regs, cols i on lanes) = kf^T W^T + ST^T g^T + ksum (x) dden
-            f32x16 Q = zero16();
-            const int nks = wi == 0 ? 2 : 4;    // j <= i: for i-half 0 only j-half 0 contributes
-#pragma unroll 2
-            for (int s = 0; s < nks; ++s)
+            put_acc_T_all(es, 32 * wj + l31, 32 * wi, st, hf);
+            if (wi == 0 && hf == 0) ksm[32 * wj + l31] = sa[0];
+        }
+        __syncthreads();
+        // ---- phase 2: the products
+        if (kvg) {
+            const bf16_t* rs = er + b * TILE;            // R behind this chunk
+            // dkf^T tile (rows e on regs, cols j on lanes) = R v^T + qf^T W + r1 (x) 1 ; j-half wi: over i >= j only
+            f32x16 K = prod_rows4(rs, 32 * wj + l31, vs, 32 * wi + l31, hf);
+            K = mfma(first_if(hf == 0, r1s[b][32 * wj + l31]), one0, K);
+            // dv^T tile (rows m on regs, cols j on lanes) = R^T kf^T + g^T A
+            f32x16 V = mfma(tfrag8(rs, 0, 32 * wj, lane), row8(ks, 32 * wi + l31, 8 * hf), zero16());
+#pragma unroll
+            for (int s = 1; s < 4; ++s)
+                V = mfma(tfrag8(rs, 16 * s, 32 * wj, lane), row8(ks, 32 * wi + l31, 16 * s + 8 * hf), V);
+            __builtin_amdgcn_sched_barrier(0);
+            if (wi == 0) {
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    K = mfma(tfrag8(qs, 16 * s, 32 * wj, lane), row8(wt, 32 * wi + l31, 16 * s + 8 * hf), K);
+                    V = mfma(tfrag8(gs, 16 * s, 32 * wj, lane), row8(at, 32 * wi + l31, 16 * s + 8 * hf), V);
+                }
+            }
+#pragma unroll
+            for (int s = 2; s < 4; ++s) {
+                K = mfma(tfrag8(qs, 16 * s, 32 * wj, lane), row8(wt, 32 * wi + l31, 16 * s + 8 * hf), K);
+                V = mfma(tfrag8(gs, 16 * s, 32 * wj, lane), row8(at, 32 * wi + l31, 16 * s + 8 * hf), V);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            put_acc_T_dphi(ok_, ks, 32 * wi + l31, 32 * wj, K, hf);
+            put_acc_T_all(ov, 32 * wi + l31, 32 * wj, V, hf);
+        } else {
+            // dqf^T tile (rows e on regs, cols i on lanes) = S g^T + kf^T W^T + ksum (x) dden ; i-half wi: over j <= i only
+            f32x16 Q = prod_rows4(es, 32 * wj + l31, gs, 32 * wi + l31, hf);
+            Q = mfma(first_if(hf == 0, ksm[32 * wj + l31]), first_if(hf == 0, dden_i), Q);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
                 Q = mfma(tfrag8(ks, 16 * s, 32 * wj, lane), tfrag8(wt, 16 * s, 32 * wi, lane), Q);
-            Q = prod_accA(Q, st0, st1, gs, 32 * wi + l31, hf);
-            Q = mfma(first_if(hf == 0, st2[0]), first_if(hf == 0, dden_i), Q);
+            if (wi == 1) {
+#pragma unroll
+                for (int s = 2; s < 4; ++s)
+                    Q = mfma(tfrag8(ks, 16 * s, 32 * wj, lane), tfrag8(wt, 16 * s, 32 * wi, lane), Q);
+            }
             put_acc_T_dphi(oq, qs, 32 * wi + l31, 32 * wj, Q, hf);
         }
         __syncthreads();
@@ -941,12 +995,12 @@ __global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
     ChunkRegs RA, RB;
     load(RA, nch - 1);
     if (nch > 1) load(RB, nch - 2);
-    stage(RA, nch - 1);
+    stage(RA, nch - 1, 0);
     if (nch > 2) load(RA, nch - 3);
     __syncthreads();
     for (int c = nch - 1; c >= 0; c -= 2) {
-        iter(c, RB);
-        if (c >= 1) iter(c - 1, RA);
+        iter(c, RB, 0);
+        if (c >= 1) iter(c - 1, RA, 1);
     }
     store(0, bs0, bs1);
 
