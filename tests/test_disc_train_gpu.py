@@ -189,3 +189,35 @@ def test_score_in_groups_equals_batch_by_batch_forward(cuda):
     assert (bn.running_mean - bn_ref.running_mean).abs().max().item() < 1e-6
     assert (bn.running_var - bn_ref.running_var).abs().max().item() < 1e-6
     assert int(bn.num_batches_tracked) == int(bn_ref.num_batches_tracked) == 3
+
+
+def test_calculate_reward_tail_keeps_one_and_missing_checkpoint_keeps_weights(cuda, tmp_path, monkeypatch):
+    """`RewardDiscri.calculate_reward` (/root/reference/dqn_policy/AIRL.py:69-91): whole batches of `batch_size` windows
+    are scored (train() mode, as `all_forward` forces), a tail shorter than a batch keeps the initial 1.0; fewer windows
+    than one batch: all ones.  No checkpoint on disk: the current weights score (differences)."""
+    from rlmg_amd.dqn_policy import AIRL, AIRL_model
+    monkeypatch.chdir(tmp_path)
+    n_class = [56, 135, 18, 87, 18, 25]
+    monkeypatch.setattr(AIRL_model, "D_MODEL", 128)
+    monkeypatch.setattr(AIRL_model, "N_LAYER", 2)
+    monkeypatch.setattr(AIRL_model, "N_HEAD", 2)
+    torch.manual_seed(5)
+    disc = AIRL.RewardDiscri(n_class, Pretrain=False)
+    disc.batch_size = 20
+    disc.disc_model.longformer.p_hidden = disc.disc_model.longformer.p_attn = 0.0      # deterministic scores
+    g = torch.Generator().manual_seed(6)
+    n, W = 53, 50
+    x = torch.stack([torch.randint(0, c, (n, W), generator=g) for c in n_class], -1)
+    done, mask = torch.zeros(n, 1), torch.ones(n, W)
+    assert not os.path.exists("./ckpt/disc_IRL.pt")
+    import copy
+    ref = copy.deepcopy(disc.disc_model).train()
+    pred = disc.calculate_reward(x, done, x, mask, mask)
+    assert pred.shape == (n, 1) and pred.device.type == "cpu"
+    assert torch.equal(pred[40:], torch.ones(13, 1))                    # the tail of 13 windows was never scored
+    with torch.no_grad():
+        want = torch.cat([ref(x[s:s + 20].long().to(cuda), mask[s:s + 20].long().to(cuda)) for s in (0, 20)], 0)
+    assert (pred[:40] - want.float().cpu()).abs().max().item() < 1e-5
+    assert (pred[:40] != 1.0).all()
+    few = disc.calculate_reward(x[:7], done[:7], x[:7], mask[:7], mask[:7])
+    assert torch.equal(few, torch.ones(7, 1))
