@@ -25,27 +25,22 @@ namespace cwlt {
 namespace gn {
 
 constexpr int TMR = 128, TNC = 256, BK = 32;
-constexpr int LDK = 40;    // staging row stride (bf16): 80 B
-constexpr int LDE = 264;   // epilogue tile row stride (bf16): 528 B
+constexpr int NSTAGE = 3;                       // LDS ring: 3 x (128 dy rows + 256 W rows) x 64 B = 72 KiB
+constexpr int STG = (TMR + TNC) * BK * 2;       // bytes of one stage (24 KiB); the W rows start at TMR * 64
+constexpr int LDE = 264;                        // epilogue tile row stride (bf16): 528 B
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ bf16x8 frag(const bf16_t* t, int row, int k) {
-    return __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(t + row * LDK + k));
-}
+typedef __attribute__((address_space(3))) void lds_void;
 
 // part: (row tiles, N) f32 column sums of this workgroup's rows of C (NULL: not wanted)
 template <bool NT_STREAMS>
 __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ G, bf16_t* __restrict__ Cout,
     float* __restrict__ part, long M, int N, int K, long lda, long ldw, long ldg, long ldc) {
-    // staging: As[2][128][40] + Ws[2][256][40] bf16 = 61 440 B; the epilogue tile [128][264] bf16 = 67 584 B reuses it
-    __shared__ __attribute__((aligned(16))) bf16_t lds[TMR * LDE];
-    bf16_t* As0 = lds;
-    bf16_t* As1 = lds + TMR * LDK;
-    bf16_t* Ws0 = lds + 2 * TMR * LDK;
-    bf16_t* Ws1 = lds + 2 * TMR * LDK + TNC * LDK;
+    // operand ring: NSTAGE x [dy rows | W rows], 64-byte rows (32 k values), unpadded; the epilogue tile
+    // [128][264] bf16 = 67 584 B reuses it
+    __shared__ __attribute__((aligned(16))) char lds[NSTAGE * STG];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -60,30 +55,68 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     const int n0 = ct * TNC;
     const long mrows = min((long)TMR, M - m0);
 
-    const __amdgpu_buffer_rsrc_t ar = make_rsrc(A + m0 * lda, (uint32_t)(((mrows - 1) * lda + K) * 2));
-    const __amdgpu_buffer_rsrc_t wr = make_rsrc(W + (long)n0 * ldw, (uint32_t)(((long)(TNC - 1) * ldw + K) * 2));
-    const int srow = tid >> 2, sk = (tid & 3) * 8;    // staging slot: row srow (and srow + 128 of W), 8 k values
-    uint4 xa0, wa0, wb0, xa1, wa1, wb1;
-#define GN_LOAD(S, k0)                                                                        \
-    {                                                                                         \
-        xa##S = buf_load16(ar, ((uint32_t)srow * (uint32_t)lda + (k0) + sk) * 2);             \
-        wa##S = buf_load16(wr, ((uint32_t)srow * (uint32_t)ldw + (k0) + sk) * 2);             \
-        wb##S = buf_load16(wr, ((uint32_t)(srow + 128) * (uint32_t)ldw + (k0) + sk) * 2);     \
+    // Staging goes global -> LDS directly (buffer_load_dwordx4 ... lds), as in wgrad.hip: no VGPR round trip and no
+    // 16-byte LDS stores (the register-staged version's ds_write_b128 had 2-way bank conflicts at the padded 80-byte
+    // row stride and, with the fragment reads, kept the LDS pipe busier than the MFMA pipe: 61 % against 30 %).  An
+    // LDS-DMA wave-instruction writes 1 KiB linearly = 16 unpadded rows; the 16-byte fragment reads of 16 consecutive
+    // rows stay conflict-free through an XOR swizzle applied on the SOURCE side: the 16-byte chunk c of row r is
+    // stored at chunk position c ^ ((r >> 2) & 3).
+    // Descriptors as four SGPRs each; rows past the tile's end read back as zeros (hardware range check).
+    const uint64_t abase = (uint64_t)(A + m0 * lda), wbase = (uint64_t)(W + (long)n0 * ldw);
+    u32x4_t ars, wrs;
+    ars[0] = __builtin_amdgcn_readfirstlane((uint32_t)abase);
+    ars[1] = __builtin_amdgcn_readfirstlane((uint32_t)(abase >> 32));
+    ars[2] = __builtin_amdgcn_readfirstlane((uint32_t)(((mrows - 1) * lda + K) * 2));
+    ars[3] = 0x00020000u;
+    wrs[0] = __builtin_amdgcn_readfirstlane((uint32_t)wbase);
+    wrs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32));
+    wrs[2] = __builtin_amdgcn_readfirstlane((uint32_t)(((long)(TNC - 1) * ldw + K) * 2));
+    wrs[3] = 0x00020000u;
+    // this wave's three DMA pieces per step: dy rows 16w .. 16w + 15, W rows 16w .. and 128 + 16w ..  Lane l lands at
+    // piece base + 16 l = (row l >> 2, chunk position l & 3), which holds chunk (l & 3) ^ ((l >> 4) & 3).
+    const int drow = 16 * w + (lane >> 2);
+    const int dchunk = (lane & 3) ^ ((lane >> 4) & 3);
+    const uint32_t a_voff = ((uint32_t)drow * (uint32_t)lda + dchunk * 8) * 2;
+    const uint32_t w_voff = ((uint32_t)drow * (uint32_t)ldw + dchunk * 8) * 2;
+    const uint32_t w_half = (uint32_t)(128 * ldw * 2);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_void*)lds + w * 1024;      // this wave's dy piece inside a stage
+    // issued from inline asm so that the waits can be counted by hand (see wgrad.hip); M0 carries the LDS address
+#define GN_DMA(stage, step)                                                                                       \
+    {                                                                                                             \
+        unsigned keep;                                                                                            \
+        const uint32_t la = lds0 + (uint32_t)(stage) * STG;                                                       \
+        const uint32_t sk_ = (uint32_t)(step) * (BK * 2), sk2 = sk_ + w_half;                                     \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"                                     \
+                     "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"                                               \
+                     "s_add_u32 m0, %3, 0x2000\n\ts_nop 0\n\t"                                                   \
+                     "buffer_load_dwordx4 %5, %6, %4 offen lds\n\t"                                               \
+                     "s_add_u32 m0, %3, 0x4000\n\ts_nop 0\n\t"                                                   \
+                     "buffer_load_dwordx4 %5, %6, %7 offen lds\n\t"                                               \
+                     "s_mov_b32 m0, %0"                                                                           \
+                     : "=&s"(keep)                                                                                \
+                     : "v"(a_voff), "s"(ars), "s"(la), "s"(sk_), "v"(w_voff), "s"(wrs), "s"(sk2)                  \
+                     : "memory", "scc");                                                                          \
     }
-#define GN_STAGE(S, Ab, Wb)                                                                   \
+    // fragment byte offsets of this lane inside a row block: row l31, chunk (2 ks + hf) at position ^ ((l31 >> 2) & 3)
+    const int swz = (l31 >> 2) & 3;
+    const int of0 = l31 * 64 + ((hf ^ swz) << 4), of1 = l31 * 64 + (((2 + hf) ^ swz) << 4);
+    const int oa = (64 * wm) * 64, ow = TMR * 64 + (64 * wn) * 64;      // wave tile bases; + 32 rows = + 2048 bytes
+#define GN_FRAG(p) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p))
+#define GN_COMPUTE(stage)                                                                     \
     {                                                                                         \
-        *reinterpret_cast<uint4*>(Ab + srow * LDK + sk) = xa##S;                              \
-        *reinterpret_cast<uint4*>(Wb + srow * LDK + sk) = wa##S;                              \
-        *reinterpret_cast<uint4*>(Wb + (srow + 128) * LDK + sk) = wb##S;                      \
-    }
-#define GN_COMPUTE(Ab, Wb)                                                                    \
-    _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                  \
-        bf16x8 fw[2], fx[2];                                                                  \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j) fw[j] = frag(Wb, 64 * wn + 32 * j + l31, 16 * ks + 8 * hf); \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i) fx[i] = frag(Ab, 64 * wm + 32 * i + l31, 16 * ks + 8 * hf); \
-        _Pragma("unroll") for (int i = 0; i < 2; ++i)                                         \
-            _Pragma("unroll") for (int j = 0; j < 2; ++j)                                     \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[j], fx[i], acc[i][j], 0, 0, 0); \
+        const char* sb = lds + (stage) * STG;                                                 \
+        const bf16x8 w00 = GN_FRAG(sb + ow + of0), w01 = GN_FRAG(sb + ow + 2048 + of0);       \
+        const bf16x8 x00 = GN_FRAG(sb + oa + of0), x01 = GN_FRAG(sb + oa + 2048 + of0);       \
+        const bf16x8 w10 = GN_FRAG(sb + ow + of1), w11 = GN_FRAG(sb + ow + 2048 + of1);       \
+        const bf16x8 x10 = GN_FRAG(sb + oa + of1), x11 = GN_FRAG(sb + oa + 2048 + of1);       \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w00, x00, acc[0][0], 0, 0, 0);    \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w01, x00, acc[0][1], 0, 0, 0);    \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w00, x01, acc[1][0], 0, 0, 0);    \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w01, x01, acc[1][1], 0, 0, 0);    \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w10, x10, acc[0][0], 0, 0, 0);    \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x10, acc[0][1], 0, 0, 0);    \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w10, x11, acc[1][0], 0, 0, 0);    \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x11, acc[1][1], 0, 0, 0);    \
     }
 
     f32x16 acc[2][2];   // [row half i][column half j]: registers = columns (n), lanes = rows (m)
@@ -94,23 +127,27 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    GN_LOAD(0, 0);
-    GN_STAGE(0, As0, Ws0);
-    GN_LOAD(0, BK);
-    __syncthreads();
-    // unrolled by two with static stage names (loads run two steps ahead); K is a multiple of 64 (launcher)
-    for (int k0 = 0; k0 < K; k0 += 2 * BK) {
-        GN_LOAD(1, k0 + 2 * BK);
-        GN_COMPUTE(As0, Ws0);
-        GN_STAGE(0, As1, Ws1);
-        __syncthreads();
-        GN_LOAD(0, k0 + 3 * BK);
-        GN_COMPUTE(As1, Ws1);
-        GN_STAGE(1, As0, Ws0);
-        __syncthreads();
+    // Ring of 3 stages, DMA two steps ahead, ONE barrier per step:
+    //   wait until this wave's pieces of step s have landed (vmcnt leaves the younger step's 3 pieces in flight);
+    //   barrier: every wave's pieces of step s have landed, and every wave has finished reading step s - 1;
+    //   issue step s + 2 into the stage step s - 1 used;  compute step s.
+    const int nstep = K / BK;                         // K is a multiple of 64 (launcher): nstep >= 2
+    GN_DMA(0, 0);
+    GN_DMA(1, 1);
+    for (int s = 0; s < nstep; ++s) {
+        if (s + 1 < nstep)
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        const int st = s % NSTAGE;
+        if (s + 2 < nstep) GN_DMA((s + 2) % NSTAGE, s + 2);
+        GN_COMPUTE(st);
     }
-#undef GN_LOAD
-#undef GN_STAGE
+    __syncthreads();                                  // every wave is done with the ring: the epilogue tile reuses it
+#undef GN_DMA
+#undef GN_FRAG
 #undef GN_COMPUTE
 
     // epilogue.  This thread's 8 chunks of the tile: rows (tid >> 5) + 16 i, columns 8 (tid & 31) .. + 7.  Their gd
@@ -130,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
 
     // f32 product * gd would need the f32 tile in LDS (135 KB); the tile is rounded to bf16 first (as the unfused
     // GEMM's output was) and multiplied in f32, rounded once more: the arithmetic of the two-kernel path.
-    bf16_t* et = lds;
+    bf16_t* et = reinterpret_cast<bf16_t*>(lds);
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
