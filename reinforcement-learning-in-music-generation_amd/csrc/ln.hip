@@ -193,16 +193,18 @@ __global__ __launch_bounds__(1024) void colsum_finalize_kernel(const float* __re
     if (col < ncols) {
         const int per = (nblocks + 15) / 16;
         const int b0 = wave * per, b1 = min(nblocks, b0 + per);
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        // 16 independent loads in flight per thread: the walk is latency-bound (a few KB per column block)
+        float a[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) a[u] = 0.f;
         int b = b0;
-        for (; b + 3 < b1; b += 4) {
-            a0 += p[(long)(b + 0) * stride + col];
-            a1 += p[(long)(b + 1) * stride + col];
-            a2 += p[(long)(b + 2) * stride + col];
-            a3 += p[(long)(b + 3) * stride + col];
+        for (; b + 15 < b1; b += 16) {
+#pragma unroll
+            for (int u = 0; u < 16; ++u) a[u] += p[(long)(b + u) * stride + col];
         }
-        for (; b < b1; ++b) a0 += p[(long)b * stride + col];
-        acc = (a0 + a1) + (a2 + a3);
+        for (; b < b1; ++b) a[0] += p[(long)b * stride + col];
+        acc = (((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]))) +
+              (((a[8] + a[9]) + (a[10] + a[11])) + ((a[12] + a[13]) + (a[14] + a[15])));
     }
     red[wave][lane] = acc;
     __syncthreads();
