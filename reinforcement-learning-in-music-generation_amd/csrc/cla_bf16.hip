@@ -41,6 +41,18 @@ constexpr int FIN_FLOATS = 65 * 64;   // per stream: the forward's final state, 
 // and of phi(k)); seg_prefix_kernel turns the increments into the state each segment starts from; the scan proper
 // then runs every segment from that state.  P == 1: one workgroup per stream, no state traffic (the default).
 // State tiles travel in accumulator-register order ([tile][register][lane] f32), so loading one is 16 coalesced loads.
+// Workgroup id -> (sequence, head) stream.  Workgroup ids are dealt round-robin over the 8 XCDs, and a token row's H
+// heads are H adjacent 128-byte pieces of one contiguous row: with the plain order the 8 heads of a sequence run on 8
+// different XCDs, each pulling its 128 bytes out of every row at its own time.  Dealing whole sequences to XCDs (all
+// heads of sequence n are neighbours in ONE XCD's dispatch order, so they walk the same rows at about the same time)
+// lets the row's DRAM page and L2 lines be shared.  N % 8 != 0: plain order.  (Measured on one box, B = 512: forward
+// 511 -> 498 us, one-sweep backward within the run-to-run noise.)
+__device__ __forceinline__ int stream_of_block(int b, int N, int H) {
+    if (N & 7) return b;
+    const int x = b & 7, j = b >> 3;
+    return ((j / H) * 8 + x) * H + j % H;
+}
+
 __device__ __forceinline__ f32x16 load_tile(const float* t, int lane) {
     f32x16 x;
 #pragma unroll
@@ -70,7 +82,8 @@ __global__ __launch_bounds__(256) void cla_fwd_bf16_kernel(const bf16_t* __restr
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wi = w >> 1, wj = w & 1;
     const int l31 = lane & 31, hf = lane >> 5;
-    const int sid = blockIdx.x / P, seg = blockIdx.x % P;      // stream, segment
+    const int seg = blockIdx.x % P;                             // segment
+    const int sid = P == 1 ? stream_of_block(blockIdx.x, gridDim.x / H, H) : blockIdx.x / P;   // stream
     const int n = sid / H, h = sid % H;
     const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
     const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
@@ -777,7 +790,7 @@ __global__ __launch_bounds__(512, 1) void cla_bwd_sweep_bf16_kernel(
     const bool kvg = w8 < 4;                       // KV group / Q group
     const int w = w8 & 3, wi = w >> 1, wj = w & 1;
     const int l31 = lane & 31, hf = lane >> 5;
-    const int sid = blockIdx.x;
+    const int sid = stream_of_block(blockIdx.x, gridDim.x / H, H);
     const int n = sid / H, h = sid % H;
     const bf16_t* qb = q + ((long)n * L) * ldq + h * D;
     const bf16_t* kb = k + ((long)n * L) * ldk + h * D;
