@@ -25,7 +25,8 @@ def _sweep(qd, kd, vd, gd):
 
 
 @pytest.mark.parametrize("N,L,H", [(1, 64, 1), (2, 128, 2), (1, 100, 1), (3, 200, 2), (1, 1024, 2), (2, 1000, 1),
-                                   (1, 4096, 1), (1, 1, 1), (1, 65, 3), (2, 192, 8)])
+                                   (1, 4096, 1), (1, 1, 1), (1, 65, 3), (2, 192, 8),
+                                   (8, 130, 3), (16, 64, 2)])      # N % 8 == 0: whole sequences dealt to XCDs
 def test_sweep_matches_oracle_and_pair(cuda, monkeypatch, N, L, H):
     monkeypatch.setenv("CWLT_SCAN_SEGMENTS", "1")
     g0 = torch.Generator().manual_seed(7 * L + H)
