@@ -164,6 +164,18 @@ int64_t cwlt_gemm_nt_tiles(int64_t M);
 int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float* part, float* colsum,
                      int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldg, int64_t ldc, void* stream);
 
+/* ---- FFN forward: linear1 + bias + GELU + dropout in the GEMM's epilogue ------------------------
+ * x = bf16(a (M, K) . w (N, K)^T) + bias (N, f32);  g = dropout_p(gelu(x)),  gd = mask * 1/(1-p) * gelu'(x):
+ * `self.dropout(self.activation(self.linear1(y)))` of fast_transformers' TransformerEncoderLayer
+ * (dqn_policy/model.py:128-137, activation='gelu' = exact erf) together with the factor cwlt_gemm_nt_mul multiplies the
+ * upstream gradient with -- what a plain GEMM followed by cwlt_bias_gelu_dropout_fwd(gd) produces (same arithmetic,
+ * the pre-activation rounded to bf16 as the GEMM's output would be, same dropout stream keyed by (seed, element
+ * index)), without the (M, N) pre-activation's write and read.  w = linear1.weight as stored, (N, K) row-major.
+ * g, gd: dense (M, N) bf16, distinct.  N % 256 == 0, K % 64 == 0, lda / ldw multiples of 8, 16-byte aligned. */
+int cwlt_gemm_nt_bias_gelu_dropout(const void* a, const void* w, const float* bias, void* g, void* gd,
+                                   int64_t M, int N, int K, int64_t lda, int64_t ldw, float p,
+                                   uint64_t seed, const uint64_t* seed_base, void* stream);
+
 /* ---- positional encoding + dropout --------------------------------------------------------------
  * y = dropout_p(x + pe[r % T]) -- PositionalEncoding.forward, dqn_policy/model.py:90-92.  pe is the
  * registered (max_len, D) f32 buffer; pe == NULL gives plain dropout, which is also this op's

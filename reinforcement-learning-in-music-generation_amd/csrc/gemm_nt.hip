@@ -19,6 +19,7 @@
 // 16-byte coalesced stores.  Operand rows come through buffer resources (hardware range check).  Workgroup ids are
 // dealt so that the column tiles of one row tile run on ONE XCD.
 #include "cwlt_common.h"
+#include "cwlt_gelu.h"
 #include <stdlib.h>
 
 namespace cwlt {
@@ -33,11 +34,21 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-// part: (row tiles, N) f32 column sums of this workgroup's rows of C (NULL: not wanted)
-template <bool NT_STREAMS>
+// Epilogue modes of the kernel:
+//   EPI_MUL   c = bf16(a w^T) * g (g read),  part: (row tiles, N) f32 column sums of c (NULL: not wanted)   [FFN backward]
+//   EPI_GELU  x = bf16(a w^T) + bias;  c = mask * keep_scale * gelu(x),  g (WRITTEN) = mask * keep_scale * gelu'(x)
+//             -- linear1 + bias + GELU + dropout of the FFN forward with the backward's factor alongside: the
+//             arithmetic, the rounding of the pre-activation to bf16 and the dropout stream (seed, element index) of
+//             cwlt_bias_gelu_dropout_fwd(gd_out) applied to a hipBLASLt product, without the pre-activation ever
+//             reaching HBM                                                                                  [FFN forward]
+enum { EPI_MUL = 0, EPI_GELU = 1 };
+
+template <int EPI, bool NT_STREAMS>
 __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
-    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, const bf16_t* __restrict__ G, bf16_t* __restrict__ Cout,
-    float* __restrict__ part, long M, int N, int K, long lda, long ldw, long ldg, long ldc) {
+    const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* G, bf16_t* __restrict__ Cout,
+    float* __restrict__ part, long M, int N, int K, long lda, long ldw, long ldg, long ldc,
+    const float* __restrict__ bias, uint32_t thresh, float keep_scale, uint64_t seed,
+    const uint64_t* __restrict__ seed_base) {
     // operand ring: NSTAGE x [dy rows | W rows], 64-byte rows (32 k values), unpadded; the epilogue tile
     // [128][264] bf16 = 67 584 B reuses it
     __shared__ __attribute__((aligned(16))) char lds[NSTAGE * STG];
@@ -150,19 +161,21 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
 #undef GN_FRAG
 #undef GN_COMPUTE
 
-    // epilogue.  This thread's 8 chunks of the tile: rows (tid >> 5) + 16 i, columns 8 (tid & 31) .. + 7.  Their gd
-    // chunks are requested first (the accumulators are still being written to LDS while they fly).
+    // epilogue.  This thread's 8 chunks of the tile: rows (tid >> 5) + 16 i, columns 8 (tid & 31) .. + 7.
     const int erow = tid >> 5, ecol = (tid & 31) * 8;
-    const __amdgpu_buffer_rsrc_t gr =
-        make_rsrc(G + m0 * ldg + n0, (uint32_t)(((mrows - 1) * ldg + TNC) * 2));      // rows >= mrows read zeros
     uint4 gv[8];
+    if (EPI == EPI_MUL) {
+        // the gd chunks are requested first (the accumulators are still being written to LDS while they fly)
+        const __amdgpu_buffer_rsrc_t gr =
+            make_rsrc(G + m0 * ldg + n0, (uint32_t)(((mrows - 1) * ldg + TNC) * 2));      // rows >= mrows read zeros
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-        // once-read stream: non-temporal (aux = 2) so that it does not evict the operand strips the co-resident
-        // workgroup's main loop re-reads from L2 (CWLT_GEMM_NT=0 builds use the default policy for A/B comparison)
-        const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-            gr, (int)(((uint32_t)(erow + 16 * i) * (uint32_t)ldg + ecol) * 2), 0, NT_STREAMS ? 2 : 0);
-        gv[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        for (int i = 0; i < 8; ++i) {
+            // once-read stream: non-temporal (aux = 2) so that it does not evict the operand strips the co-resident
+            // workgroup's main loop re-reads from L2 (CWLT_GEMM_NT=0 builds use the default policy for A/B comparison)
+            const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                gr, (int)(((uint32_t)(erow + 16 * i) * (uint32_t)ldg + ecol) * 2), 0, NT_STREAMS ? 2 : 0);
+            gv[i] = make_uint4(v[0], v[1], v[2], v[3]);
+        }
     }
 
     // f32 product * gd would need the f32 tile in LDS (135 KB); the tile is rounded to bf16 first (as the unfused
@@ -182,6 +195,54 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
             }
         }
     __syncthreads();
+    if (EPI == EPI_GELU) {
+        if (seed_base) seed += *seed_base;   // device-resident offset: a captured hipGraph draws fresh masks per replay
+        float b[8];
+        loadf<8>(bias + n0 + ecol, b);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int row = erow + 16 * i;
+            if (row < mrows) {
+                const uint4 hv = *reinterpret_cast<const uint4*>(et + row * LDE + ecol);
+                float t[8], d[8];
+                load8(reinterpret_cast<const bf16_t*>(&hv), t);
+                // element index of (row, column) in the dense (M, N) activation: what cwlt_bias_gelu_dropout_fwd keys
+                // its mask with (the launcher insists on ldc == ldg == N)
+                const uint64_t off = (uint64_t)(m0 + row) * (uint64_t)N + (uint64_t)(n0 + ecol);
+                const uint32_t km = thresh ? dropout_mask<8>(seed, off, thresh) : 0xffffffffu;
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    f32x2 x, cdf, pdf;
+                    x[0] = t[j] + b[j];
+                    x[1] = t[j + 1] + b[j + 1];
+                    gelu_parts2(x, cdf, pdf);
+                    const f32x2 y = x * cdf * keep_scale;
+                    const f32x2 dy = (x * pdf + cdf) * keep_scale;
+                    t[j] = ((km >> j) & 1u) ? y[0] : 0.f;
+                    t[j + 1] = ((km >> (j + 1)) & 1u) ? y[1] : 0.f;
+                    d[j] = ((km >> j) & 1u) ? dy[0] : 0.f;
+                    d[j + 1] = ((km >> (j + 1)) & 1u) ? dy[1] : 0.f;
+                }
+                u32x4_t r, q;
+                r[0] = f32x2_to_bf16x2(t[0], t[1]);
+                r[1] = f32x2_to_bf16x2(t[2], t[3]);
+                r[2] = f32x2_to_bf16x2(t[4], t[5]);
+                r[3] = f32x2_to_bf16x2(t[6], t[7]);
+                q[0] = f32x2_to_bf16x2(d[0], d[1]);
+                q[1] = f32x2_to_bf16x2(d[2], d[3]);
+                q[2] = f32x2_to_bf16x2(d[4], d[5]);
+                q[3] = f32x2_to_bf16x2(d[6], d[7]);
+                // g is the next GEMM's operand: default policy; gd waits for the backward: streamed past the caches
+                *reinterpret_cast<u32x4_t*>(Cout + (m0 + row) * ldc + n0 + ecol) = r;
+                u32x4_t* dst = reinterpret_cast<u32x4_t*>(G + (m0 + row) * ldg + n0 + ecol);
+                if (NT_STREAMS)
+                    __builtin_nontemporal_store(q, dst);
+                else
+                    *dst = q;
+            }
+        }
+        return;
+    }
     float cs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = 0.f;
@@ -255,12 +316,41 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
     const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
     const long nblk = mt8 * (N / gn::TNC);
     static const bool nts = [] { const char* e = getenv("CWLT_GEMM_NT"); return !(e && e[0] == '0'); }();   // A/B switch
-    hipLaunchKernelGGL(nts ? gn::gemm_nt_mul_kernel<true> : gn::gemm_nt_mul_kernel<false>, dim3((unsigned)nblk),
-                       dim3(512), 0, st, (const bf16_t*)a, (const bf16_t*)w, (const bf16_t*)g, (bf16_t*)c, part,
-                       (long)M, N, K, (long)lda, (long)ldw, (long)ldg, (long)ldc);
+    auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_MUL, true> : gn::gemm_nt_mul_kernel<gn::EPI_MUL, false>;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, st, (const bf16_t*)a, (const bf16_t*)w,
+                       const_cast<bf16_t*>((const bf16_t*)g), (bf16_t*)c, part, (long)M, N, K, (long)lda, (long)ldw,
+                       (long)ldg, (long)ldc, (const float*)nullptr, 0u, 1.0f, (uint64_t)0, (const uint64_t*)nullptr);
     int e = (int)hipGetLastError();
     if (e || !colsum) return e;
     return launch_colsum_finalize(part, colsum, (int)mtiles, (long)N, N, 1.0f, 0, st);
+}
+
+/* FFN forward in one kernel:  x = bf16(a (M, K) . w (N, K)^T) + bias (N) f32;  g = dropout(gelu(x)),
+ * gd = mask * keep_scale * gelu'(x)  -- `self.dropout(self.activation(self.linear1(y)))` of fast_transformers'
+ * TransformerEncoderLayer (/root/reference/dqn_policy/model.py:128-137) with the factor its backward needs
+ * (cwlt_gemm_nt_mul's `g`).  Same arithmetic, same rounding of the pre-activation and same dropout stream as a plain
+ * GEMM followed by cwlt_bias_gelu_dropout_fwd(gd_out); the pre-activation never reaches HBM.  g and gd: dense (M, N)
+ * bf16 (the mask is keyed by the element index).  N % 256 == 0, K % 64 == 0, lda / ldw multiples of 8, 16-byte
+ * aligned pointers, 0 <= p < 1. */
+int cwlt_gemm_nt_bias_gelu_dropout(const void* a, const void* w, const float* bias, void* g, void* gd, int64_t M, int N,
+                                   int K, int64_t lda, int64_t ldw, float p, uint64_t seed, const uint64_t* seed_base,
+                                   void* stream) {
+    using namespace cwlt;
+    if (M < 0 || N <= 0 || K <= 0 || (N % gn::TNC) || (K % 64) || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (M == 0) return CWLT_OK;
+    if (!a || !w || !bias || !g || !gd || g == gd) return CWLT_ERR_ARG;
+    if (((lda | ldw) & 7) || lda < K || ldw < K) return CWLT_ERR_ARG;
+    if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)g | (uintptr_t)gd | (uintptr_t)bias) & 15) return CWLT_ERR_ARG;
+    if ((int64_t)gn::TMR * lda * 2 >= (1ll << 31) || (int64_t)gn::TNC * ldw * 2 >= (1ll << 31)) return CWLT_ERR_ARG;
+    const long mtiles = (M + gn::TMR - 1) / gn::TMR;
+    const long mt8 = (mtiles + 7) / 8 * 8;
+    const long nblk = mt8 * (N / gn::TNC);
+    static const bool nts = [] { const char* e = getenv("CWLT_GEMM_NT"); return !(e && e[0] == '0'); }();
+    auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_GELU, true> : gn::gemm_nt_mul_kernel<gn::EPI_GELU, false>;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
+                       (bf16_t*)gd, (bf16_t*)g, (float*)nullptr, (long)M, N, K, (long)lda, (long)ldw, (long)N, (long)N,
+                       bias, drop_thresh(p), drop_scale(p), seed, seed_base);
+    return (int)hipGetLastError();
 }
 
 }  // extern "C"

@@ -22,6 +22,8 @@ from . import ops
 
 # CWLT_FUSED_FFN_BWD=0: keep the two-kernel FFN backward (hipBLASLt input-gradient GEMM + cwlt_bias_gelu_dropout_bwd)
 FUSED_FFN_BWD = os.environ.get("CWLT_FUSED_FFN_BWD", "1") != "0"
+# CWLT_FUSED_FFN_FWD=0: linear1 through hipBLASLt followed by cwlt_bias_gelu_dropout_fwd instead of the one-kernel form
+FUSED_FFN_FWD = os.environ.get("CWLT_FUSED_FFN_FWD", "1") != "0"
 
 
 class TriangularCausalMask:
@@ -64,12 +66,18 @@ class _EncoderLayerFn(torch.autograd.Function):
         o = torch.addmm(bo_a, a2, wo_a.t())                                # MFMA
         s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
         del o
-        h = torch.mm(x1, w1_a.t())                                         # (R, F)  MFMA, bias in next kernel
-        # bf16, when a backward will follow: the activation kernel overwrites h with gd = mask / (1 - p) * gelu'(h + b1); the backward then needs no
-        # activation pass at all -- dh = (dy . W2) * gd leaves the input-gradient GEMM's epilogue (ops.gemm_nt_mul)
+        # bf16, when a backward will follow: the activation pass also leaves gd = mask / (1 - p) * gelu'(h + b1) (in place
+        # of h); the backward then needs no activation pass at all -- dh = (dy . W2) * gd leaves the input-gradient GEMM's
+        # epilogue (ops.gemm_nt_mul).  The forward does the same from its side: linear1, bias, GELU and dropout are ONE
+        # kernel (ops.ffn1_gelu_dropout), the pre-activation never reaches HBM.
         fused_ffn = (FUSED_FFN_BWD and adt == torch.bfloat16 and any(ctx.needs_input_grad)
-                     and h.is_contiguous() and h.shape[1] % 256 == 0 and D % 64 == 0)
-        g = ops.gelu_fwd(h, b1f, p, seeds[1], gd_inplace=fused_ffn)
+                     and D % 64 == 0 and w1_a.shape[0] % 256 == 0)
+        if fused_ffn and FUSED_FFN_FWD and ops.ffn1_fused_supported(x1, w1_a, b1f):
+            g, h = ops.ffn1_gelu_dropout(x1, w1_a, b1f, p, seeds[1])      # h holds gd
+        else:
+            h = torch.mm(x1, w1_a.t())                                     # (R, F)  MFMA, bias in next kernel
+            fused_ffn = fused_ffn and h.is_contiguous()
+            g = ops.gelu_fwd(h, b1f, p, seeds[1], gd_inplace=fused_ffn)
         y = torch.addmm(b2_a, g, w2_a.t())                                 # MFMA
         s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
         del y

@@ -601,6 +601,27 @@ def gemm_nt_mul(a, w, g, want_colsum=True):
     return (c, cs) if want_colsum else c
 
 
+def ffn1_fused_supported(x, w, bias):
+    return (x.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and bias.dtype == torch.float32 and x.dim() == 2
+            and w.dim() == 2 and w.shape[0] % 256 == 0 and x.shape[1] % 64 == 0 and x.shape[1] == w.shape[1]
+            and bias.numel() == w.shape[0] and bias.is_contiguous() and bias.data_ptr() % 16 == 0
+            and all(t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in (x, w)))
+
+
+def ffn1_gelu_dropout(x, w, bias, p=0.0, seed=0):
+    """g = dropout(gelu(x @ w.T + bias)) and gd = mask / (1 - p) * gelu'(x @ w.T + bias) in ONE kernel (the GEMM's
+    epilogue): what `torch.mm` + `gelu_fwd(..., gd_inplace=True)` produce, without the pre-activation's round trip
+    through HBM.  x (M, K), w (N, K) bf16, bias (N) f32 -> g, gd (M, N) bf16."""
+    _lib.load()
+    M, K = x.shape
+    N = w.shape[0]
+    g = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    gd = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    _call("cwlt_gemm_nt_bias_gelu_dropout", _lib.dev(x, "x"), _lib.dev(w, "w"), _lib.dev(bias), _lib.dev(g), _lib.dev(gd),
+          M, N, K, x.stride(0), w.stride(0), float(p), int(seed), _seed_base(), _lib.stream_ptr(), work=2.0 * M * N * K)
+    return g, gd
+
+
 def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
     lib = _lib.load()
     rows, F = h.shape

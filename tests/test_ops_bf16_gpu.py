@@ -239,3 +239,48 @@ def test_gemm_nt_mul_epilogue_and_column_sums(cuda, M, N, K):
     # the unfused pair it replaces: torch.mm -> bf16, times gd
     unf = (torch.mm(a.to(cuda), w.to(cuda).t()).float() * gd.to(cuda).float()).bfloat16()
     assert (c.float() - unf.float()).abs().max().item() <= 2 * BF16_TOL * scale
+
+
+@pytest.mark.parametrize("M,N,K,p", [(128, 256, 64, 0.0), (129, 512, 512, 0.1), (1000, 2048, 512, 0.1), (4096, 2048, 512, 0.1),
+                                     (7, 256, 128, 0.5)])
+def test_ffn1_fused_equals_gemm_then_activation_kernel(cuda, M, N, K, p):
+    """g, gd of cwlt_gemm_nt_bias_gelu_dropout (linear1 + bias + GELU + dropout in the GEMM's epilogue) against
+    (a) the f64 chain on the bf16-rounded product, (b) the two-kernel path it replaces -- torch.mm (bf16 out) followed by
+    cwlt_bias_gelu_dropout_fwd with gd: same mask (same seed, same element index), values equal wherever the two GEMMs
+    rounded the pre-activation alike."""
+    g0 = torch.Generator().manual_seed(M + N + K)
+    x = _bf(torch.randn(M, K, generator=g0))
+    w = _bf(torch.randn(N, K, generator=g0) * 0.08)
+    b = torch.randn(N, generator=g0) * 0.2
+    xd, wd, bd = x.to(cuda), w.to(cuda), b.to(cuda)
+    seed = 1234 + M
+    assert ops.ffn1_fused_supported(xd, wd, bd)
+    g, gd = ops.ffn1_gelu_dropout(xd, wd, bd, p, seed)
+    h = torch.mm(xd, wd.t())                                   # bf16 pre-activation, the two-kernel path
+    hh = h.clone()
+    g2 = ops.gelu_fwd(hh, bd, p, seed, gd_inplace=True)         # hh now holds gd
+    # (a) f64 reference on the fused kernel's own rounding of the product
+    prod = (x.double() @ w.double().t())
+    pre = prod.bfloat16().double() + b.double()
+    keep = (g.float().cpu() != 0) | (gd.float().cpu() != 0)     # mask as the kernel drew it
+    keep2 = (g2.float().cpu() != 0) | (hh.float().cpu() != 0)
+    if p > 0:
+        frac = 1.0 - keep.double().mean().item()
+        assert abs(frac - p) < 0.02 + 3.0 / (M * N) ** 0.5, frac
+    same_h = (h.float().cpu() == prod.bfloat16().float())       # where hipBLASLt rounded like the f64 product
+    assert same_h.double().mean().item() > 0.97
+    assert torch.equal(keep[same_h], keep2[same_h])             # same dropout stream
+    scale = 1.0 / (1.0 - p) if p > 0 else 1.0
+    pr = pre.clone().requires_grad_(True)
+    F.gelu(pr).sum().backward()
+    ref_g = F.gelu(pre) * keep.double() * scale
+    ref_gd = pr.grad * keep.double() * scale
+    # tolerance: the pre-activation's bf16 rounding may differ by one ulp from the f64 product's (f32 accumulation order)
+    tol = BF16_TOL * max(1.0, pre.abs().max().item()) * scale
+    assert (g.double().cpu() - ref_g).abs().max().item() <= 2 * tol
+    assert (gd.double().cpu() - ref_gd).abs().max().item() <= 2 * tol
+    # (b) where both GEMMs produced the same bf16 pre-activation the outputs are bit-identical
+    both = same_h & (((g.float().cpu() - g2.float().cpu()).abs() <= tol))
+    eq = (g.cpu() == g2.cpu()) & (gd.cpu() == hh.cpu())
+    assert eq[same_h].double().mean().item() > 0.999
+    assert both.double().mean().item() > 0.97

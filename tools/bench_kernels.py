@@ -92,7 +92,30 @@ def bench_ffn2_dgrad():
     print("       net per layer: %.1f us saved" % ((t0 + t1 - t4 - (t3 - t2)) * 1e3))
 
 
+def bench_ffn1():
+    """FFN forward: hipBLASLt GEMM (h = x . W1^T) + cwlt_bias_gelu_dropout_fwd (g, gd)   vs   cwlt_gemm_nt_bias_gelu_dropout."""
+    dev = torch.device("cuda:0")
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 524288
+    x = torch.randn(M, 512, device=dev).bfloat16()
+    w1 = (torch.randn(2048, 512, device=dev) * 0.05).bfloat16()
+    b = torch.randn(2048, device=dev) * 0.1
+    t0 = timeit(lambda: torch.mm(x, w1.t()))
+    h = torch.mm(x, w1.t())
+    t1 = timeit(lambda: ops.gelu_fwd(h, b, 0.1, 77, gd_inplace=True))
+    t2 = timeit(lambda: ops.ffn1_gelu_dropout(x, w1, b, 0.1, 77))
+    fl = 2.0 * M * 512 * 2048
+    print("M=%d  unfused: mm %.1f us (%.0f TF) + activation with gd %.1f us = %.1f us" %
+          (M, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, (t0 + t1) * 1e3))
+    print("       fused cwlt_gemm_nt_bias_gelu_dropout %.1f us (%.0f TF, %.0f GB/s of output)" %
+          (t2 * 1e3, fl / t2 / 1e9, M * (512 + 2 * 2048) * 2 / t2 / 1e6))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "ffn1":
+        from rlmg_amd import gemm_tuning
+        gemm_tuning.enable()
+        bench_ffn1()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ffn2d":
         from rlmg_amd import gemm_tuning
         gemm_tuning.enable()
