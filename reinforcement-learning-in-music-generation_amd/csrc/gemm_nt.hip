@@ -48,7 +48,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* G, bf16_t* __restrict__ Cout,
     float* __restrict__ part, long M, int N, int K, long lda, long ldw, long ldg, long ldc,
     const float* __restrict__ bias, uint32_t thresh, float keep_scale, uint64_t seed,
-    const uint64_t* __restrict__ seed_base) {
+    const uint64_t* __restrict__ seed_base, int spread) {
     // operand ring: NSTAGE x [dy rows | W rows], 64-byte rows (32 k values), unpadded; the epilogue tile
     // [128][264] bf16 = 67 584 B reuses it
     __shared__ __attribute__((aligned(16))) char lds[NSTAGE * STG];
@@ -64,6 +64,12 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     const long m0 = mt * TMR;
     if (m0 >= M) return;
     const int n0 = ct * TNC;
+    // The first resident workgroups all start together and every tile takes the same time, so without this the whole
+    // chip alternates between a phase in which nobody touches HBM (main loops) and one in which everybody stores
+    // (epilogues).  A start offset of 0..7 x ~4 us for the first two workgroups of every CU spreads the epilogues over
+    // the tile time; later workgroups inherit the spread from the ones they replace.
+    if (spread && blockIdx.x < 2 * 256 && gridDim.x > 2 * 256)
+        for (int i = (blockIdx.x >> 3) & 7; i > 0; --i) __builtin_amdgcn_s_sleep(127);
     const long mrows = min((long)TMR, M - m0);
 
     // Staging goes global -> LDS directly (buffer_load_dwordx4 ... lds), as in wgrad.hip: no VGPR round trip and no
@@ -137,6 +143,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    float b[8];                                       // EPI_GELU: this thread's 8 bias values, fetched under the main loop
+    if (EPI == EPI_GELU) loadf<8>(bias + n0 + (tid & 31) * 8, b);
 
     // Ring of 3 stages, DMA two steps ahead, ONE barrier per step:
     //   wait until this wave's pieces of step s have landed (vmcnt leaves the younger step's 3 pieces in flight);
@@ -197,8 +205,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     __syncthreads();
     if (EPI == EPI_GELU) {
         if (seed_base) seed += *seed_base;   // device-resident offset: a captured hipGraph draws fresh masks per replay
-        float b[8];
-        loadf<8>(bias + n0 + ecol, b);
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
             const int row = erow + 16 * i;
@@ -209,19 +215,31 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
                 // element index of (row, column) in the dense (M, N) activation: what cwlt_bias_gelu_dropout_fwd keys
                 // its mask with (the launcher insists on ldc == ldg == N)
                 const uint64_t off = (uint64_t)(m0 + row) * (uint64_t)N + (uint64_t)(n0 + ecol);
-                const uint32_t km = thresh ? dropout_mask<8>(seed, off, thresh) : 0xffffffffu;
+                // The keep flags of dropout_mask<8>(seed, off, thresh), bit for bit, in the form this VALU-bound epilogue
+                // can afford: the four pair indices (off >> 1) + 0..3 share their upper word and key (off is a multiple
+                // of 8, so the low word does not carry), and (lo + j) * C = lo * C + j * C -- one 32-bit multiply
+                // (quarter rate) instead of four in front of the four hashes; each 16-bit half is compared directly and
+                // becomes a keep_scale-or-zero factor instead of a bit that is packed and unpacked again.
+                const uint64_t pair0 = off >> 1;
+                const uint32_t plo = (uint32_t)pair0, phi = (uint32_t)(pair0 >> 32);
+                const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9u) ^ (phi * 0x85ebca6bu);
+                const uint32_t base = plo * 0x9e3779b1u;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
+                    const uint32_t rr = hash32((base + (uint32_t)(j >> 1) * 0x9e3779b1u) ^ key);
+                    f32x2 ks;
+                    ks[0] = (!thresh || (rr & 0xffffu) >= thresh) ? keep_scale : 0.f;
+                    ks[1] = (!thresh || (rr >> 16) >= thresh) ? keep_scale : 0.f;
                     f32x2 x, cdf, pdf;
                     x[0] = t[j] + b[j];
                     x[1] = t[j + 1] + b[j + 1];
                     gelu_parts2(x, cdf, pdf);
-                    const f32x2 y = x * cdf * keep_scale;
-                    const f32x2 dy = (x * pdf + cdf) * keep_scale;
-                    t[j] = ((km >> j) & 1u) ? y[0] : 0.f;
-                    t[j + 1] = ((km >> (j + 1)) & 1u) ? y[1] : 0.f;
-                    d[j] = ((km >> j) & 1u) ? dy[0] : 0.f;
-                    d[j + 1] = ((km >> (j + 1)) & 1u) ? dy[1] : 0.f;
+                    const f32x2 y = x * cdf * ks;
+                    const f32x2 dy = (x * pdf + cdf) * ks;
+                    t[j] = y[0];
+                    t[j + 1] = y[1];
+                    d[j] = dy[0];
+                    d[j + 1] = dy[1];
                 }
                 u32x4_t r, q;
                 r[0] = f32x2_to_bf16x2(t[0], t[1]);
@@ -290,6 +308,11 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
 }  // namespace gn
 }  // namespace cwlt
 
+static int spread_starts() {   // CWLT_GEMM_NT_SPREAD=0: all workgroups start at once (A/B switch)
+    static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_SPREAD"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
+
 extern "C" {
 
 /* Row tiles of cwlt_gemm_nt_mul = rows of its column-sum partials. */
@@ -319,7 +342,7 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
     auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_MUL, true> : gn::gemm_nt_mul_kernel<gn::EPI_MUL, false>;
     hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, st, (const bf16_t*)a, (const bf16_t*)w,
                        const_cast<bf16_t*>((const bf16_t*)g), (bf16_t*)c, part, (long)M, N, K, (long)lda, (long)ldw,
-                       (long)ldg, (long)ldc, (const float*)nullptr, 0u, 1.0f, (uint64_t)0, (const uint64_t*)nullptr);
+                       (long)ldg, (long)ldc, (const float*)nullptr, 0u, 1.0f, (uint64_t)0, (const uint64_t*)nullptr, spread_starts());
     int e = (int)hipGetLastError();
     if (e || !colsum) return e;
     return launch_colsum_finalize(part, colsum, (int)mtiles, (long)N, N, 1.0f, 0, st);
@@ -349,7 +372,7 @@ int cwlt_gemm_nt_bias_gelu_dropout(const void* a, const void* w, const float* bi
     auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_GELU, true> : gn::gemm_nt_mul_kernel<gn::EPI_GELU, false>;
     hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
                        (bf16_t*)gd, (bf16_t*)g, (float*)nullptr, (long)M, N, K, (long)lda, (long)ldw, (long)N, (long)N,
-                       bias, drop_thresh(p), drop_scale(p), seed, seed_base);
+                       bias, drop_thresh(p), drop_scale(p), seed, seed_base, spread_starts());
     return (int)hipGetLastError();
 }
 
