@@ -305,6 +305,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     }
 }
 
+
 }  // namespace gn
 }  // namespace cwlt
 

@@ -242,7 +242,9 @@ def test_gemm_nt_mul_epilogue_and_column_sums(cuda, M, N, K):
 
 
 @pytest.mark.parametrize("M,N,K,p", [(128, 256, 64, 0.0), (129, 512, 512, 0.1), (1000, 2048, 512, 0.1), (4096, 2048, 512, 0.1),
-                                     (7, 256, 128, 0.5)])
+                                     (7, 256, 128, 0.5),
+                                     # more tiles than resident workgroups, padding row tiles, a ragged last row tile
+                                     (40000, 2048, 512, 0.1), (33000, 512, 512, 0.1), (70000, 256, 1024, 0.1)])
 def test_ffn1_fused_equals_gemm_then_activation_kernel(cuda, M, N, K, p):
     """g, gd of cwlt_gemm_nt_bias_gelu_dropout (linear1 + bias + GELU + dropout in the GEMM's epilogue) against
     (a) the f64 chain on the bf16-rounded product, (b) the two-kernel path it replaces -- torch.mm (bf16 out) followed by
