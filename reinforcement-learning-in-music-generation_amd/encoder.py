@@ -41,7 +41,11 @@ class _EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, wq, bq, wk, bk, wv, bv, wo, bo, w1, b1, w2, b2, g1, be1, g2, be2, H, p, seeds, layer,
-                shadow=None):
+                shadow=None, grad_mode=True):
+        # `grad_mode`: torch.is_grad_enabled() at the call site.  Inside forward() autograd has switched it off, and
+        # ctx.needs_input_grad is true for the parameters even under torch.no_grad() -- without the flag every inference
+        # and rollout pass would pay for what only a backward needs (the gd output, the scan's final state).
+        will_backward = bool(grad_mode) and any(ctx.needs_input_grad)
         N, L, D = x.shape
         R = N * L
         adt = x.dtype
@@ -60,7 +64,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         qkv5 = qkv.view(N, L, 3, H, D // H)
         # with a backward to follow, the bf16 scan also hands over its final state: the backward is then one sweep
         _, _, _, a, zinv, fin = ops.cla_fwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2],
-                                            final_state=any(ctx.needs_input_grad))
+                                            final_state=will_backward)
         ctx.fin = fin
         a2 = a.view(R, D)
         o = torch.addmm(bo_a, a2, wo_a.t())                                # MFMA
@@ -70,7 +74,7 @@ class _EncoderLayerFn(torch.autograd.Function):
         # of h); the backward then needs no activation pass at all -- dh = (dy . W2) * gd leaves the input-gradient GEMM's
         # epilogue (ops.gemm_nt_mul).  The forward does the same from its side: linear1, bias, GELU and dropout are ONE
         # kernel (ops.ffn1_gelu_dropout), the pre-activation never reaches HBM.
-        fused_ffn = (FUSED_FFN_BWD and adt == torch.bfloat16 and any(ctx.needs_input_grad)
+        fused_ffn = (FUSED_FFN_BWD and adt == torch.bfloat16 and will_backward
                      and D % 64 == 0 and w1_a.shape[0] % 256 == 0)
         if fused_ffn and FUSED_FFN_FWD and ops.ffn1_fused_supported(x1, w1_a, b1f):
             g, h = ops.ffn1_gelu_dropout(x1, w1_a, b1f, p, seeds[1])      # h holds gd
@@ -153,12 +157,12 @@ class _EncoderLayerFn(torch.autograd.Function):
                                (layer.linear2.weight, dw2), (layer.linear2.bias, db2),
                                (layer.norm1.weight, dg1), (layer.norm1.bias, dbe1),
                                (layer.norm2.weight, dg2), (layer.norm2.bias, dbe2)))
-            return (dx.view(N, L, D),) + (None,) * 21
+            return (dx.view(N, L, D),) + (None,) * 22
         dwqkv = dwqkv.float()
         return (dx.view(N, L, D),
                 dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
                 dwo.float(), dbo, dw1.float(), db1, dw2.float(), db2, dg1, dbe1, dg2, dbe2,
-                None, None, None, None, None)
+                None, None, None, None, None, None)
 
 
 class AttentionLayer(nn.Module):
@@ -201,7 +205,8 @@ class TransformerEncoderLayer(nn.Module):
             x, at.query_projection.weight, at.query_projection.bias, at.key_projection.weight, at.key_projection.bias,
             at.value_projection.weight, at.value_projection.bias, at.out_projection.weight, at.out_projection.bias,
             self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias,
-            self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, at.n_heads, p, seeds, self, shadow)
+            self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, at.n_heads, p, seeds, self, shadow,
+            torch.is_grad_enabled())
 
 
 class TransformerEncoder(nn.Module):

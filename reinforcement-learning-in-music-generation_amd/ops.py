@@ -400,10 +400,11 @@ def _seg_ws(N, H, P, backward, device):
 SCAN_SWEEP = os.environ.get("CWLT_SCAN_SWEEP", "1") != "0"
 
 
-def cla_fwd(q, k, v, eps=CLA_EPS, final_state=False):
+def cla_fwd(q, k, v, eps=CLA_EPS, final_state=None):
     """q, k, v: (N, L, H, 64) views (row-strided ok) -> out (N, L, H, 64) dense, zinv (N, L, H) f32
     [, fin: the scan's final state for `cla_bwd(final_state=fin)`, or None where the one-sweep backward does not apply
-    (f32, odd row strides, segmented few-stream launches) -- only with final_state=True]."""
+    (f32, odd row strides, segmented few-stream launches) or final_state is False -- a sixth element whenever
+    final_state is given (True / False) at all]."""
     lib = _lib.load()
     N, L, H, D = q.shape
     if k.shape != q.shape or v.shape != q.shape:
@@ -424,7 +425,7 @@ def cla_fwd(q, k, v, eps=CLA_EPS, final_state=False):
     _call("cwlt_causal_linear_fwd", _lib.dev(q, "q"), _lib.dev(k, "k"), _lib.dev(v, "v"), _lib.dev(out), _lib.dev(zinv),
         N, H, L, D, ldq, ldk, ldv, H * D, float(eps), P, _lib.opt(ws), _lib.opt(fin), _lib.dtype_code(q.dtype),
         _lib.stream_ptr())
-    if final_state:
+    if final_state is not None:
         return q, k, v, out, zinv, fin
     return q, k, v, out, zinv
 
@@ -483,8 +484,9 @@ class CausalLinearAttentionFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, q, k, v, eps=CLA_EPS):
-        q, k, v, out, zinv, fin = cla_fwd(q, k, v, eps, final_state=True)
+    def forward(ctx, q, k, v, eps=CLA_EPS, grad_mode=True):
+        # grad_mode = torch.is_grad_enabled() at the call site (inside forward() it is off; see encoder._EncoderLayerFn)
+        q, k, v, out, zinv, fin = cla_fwd(q, k, v, eps, final_state=bool(grad_mode) and any(ctx.needs_input_grad))
         ctx.save_for_backward(q, k, v, out, zinv)
         ctx.fin = fin
         return out
@@ -493,11 +495,11 @@ class CausalLinearAttentionFn(torch.autograd.Function):
     def backward(ctx, dout):
         q, k, v, out, zinv = ctx.saved_tensors
         dqkv = cla_bwd(q, k, v, out, zinv, dout, final_state=ctx.fin)
-        return dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], None
+        return dqkv[:, :, 0], dqkv[:, :, 1], dqkv[:, :, 2], None, None
 
 
 def causal_linear_attention(q, k, v, eps=CLA_EPS):
-    return CausalLinearAttentionFn.apply(q, k, v, eps)
+    return CausalLinearAttentionFn.apply(q, k, v, eps, torch.is_grad_enabled())
 
 
 # --------------------------------------------------------------------------------------------------
