@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Benchmark of the hot path: agent pretrain step of the CW Linear Transformer at repo dims.
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W          (N > 1: under torch.distributed.run, or plain -- the
+                                                            script then starts the N ranks itself, bench_launch.py)
 
 Workload = BASELINE.json configs[1]: full agent pretrain (d_model 512, 12 layers, 8 heads, d_ff 2048;
 dqn vocabulary [56,135,18,87,18,25]) on synthetic (B, T=1024, 7-field) compound-word sequences,
@@ -19,6 +20,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    # `--gpus N` (N > 1) without a launcher's rank environment: start the ranks as a child torch.distributed.run and
+    # relay its line and exit code -- before anything in this process could touch the GPU
+    import bench_launch
+    _rc = bench_launch.maybe_self_launch(__file__)
+    if _rc is not None:
+        raise SystemExit(_rc)
 
 import torch  # noqa: E402
 
@@ -233,7 +242,9 @@ def ppo_report(args, ppo, world):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node; N > 1 outside a launcher starts torch.distributed.run itself")
+    ap.add_argument("--dry-run-launch", action="store_true", help="print the rank launcher's command line and exit")
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=512, help="sequences per GPU")

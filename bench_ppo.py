@@ -2,7 +2,8 @@
 """PPO + IRL fine-tuning throughput (BASELINE.json configs[2]: R parallel rollouts, window W).
 
     python bench_ppo.py --gpus N --rollouts 64 --window 1024 --iters K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench_ppo.py --gpus N ...)
+    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench_ppo.py --gpus N ..., or plain: the script
+     then starts the N ranks itself as a child torch.distributed.run, bench_launch.py)
 
 One iteration = the body of the reference's outer loop (ppo_policy/ppo_train.py:460-506), generalised from
 one rollout to R rollouts per GPU run in lock-step:
@@ -27,6 +28,14 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+if __name__ == "__main__":
+    # `--gpus N` (N > 1) without a launcher's rank environment: start the ranks as a child torch.distributed.run and
+    # relay its line and exit code -- before anything in this process could touch the GPU
+    import bench_launch
+    _rc = bench_launch.maybe_self_launch(__file__)
+    if _rc is not None:
+        raise SystemExit(_rc)
 
 import torch  # noqa: E402
 
@@ -189,7 +198,9 @@ def cpu_rollout_baseline(window=1024, seconds_budget=20.0):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="ranks = GPUs of this node; N > 1 outside a launcher starts torch.distributed.run itself")
+    ap.add_argument("--dry-run-launch", action="store_true", help="print the rank launcher's command line and exit")
     ap.add_argument("--rollouts", type=int, default=64, help="parallel rollouts per GPU")
     ap.add_argument("--window", type=int, default=1024)
     ap.add_argument("--episodes", type=int, default=30)
