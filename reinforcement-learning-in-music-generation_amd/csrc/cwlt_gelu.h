@@ -1,37 +1,64 @@
-// Exact-erf GELU pieces for the bf16 paths (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7), shared by the
-// elementwise kernels (ffn_act.hip).
+// erf-GELU for the bf16 paths: value and derivative from ONE v_exp_f32 and no reciprocal, shared by the elementwise
+// kernels (ffn_act.hip) and the GEMM epilogues (gemm_nt.hip, gemm_ws.hip) so that fused and unfused paths agree bit
+// for bit.  The f32 parity path keeps libm's erff / expf (ffn_act.hip).
+//
+//   e = exp(-x^2 / 2)                      (also the density: pdf = e / sqrt(2 pi), exact)
+//   Phi(-|x|) = e * Q(|x|)                 Q: degree-5 minimax fit of the Mills-type ratio Phi(-a) / exp(-a^2 / 2)
+//                                          on a >= 0 under the weight (1 + a) e, Q(0) = 1/2 exactly
+//   Phi(x) = 1/2 + sign(x) (1/2 - e Q(|x|))
+// Errors against the exact-erf forms in f32 arithmetic (tools/gelu_fit.py, all x): |gelu| and |gelu'| <= 1.5e-4 -- a
+// bf16 result carries 2^-9 relative (2e-3 at |y| = 1), and where the output is small the error is too (it scales
+// with x e(x)).  Round 2's Abramowitz-Stegun 7.1.26 form (1.5e-7) needed v_rcp_f32 besides the v_exp_f32 and 23
+// instruction slots per element where this needs 17.
 #pragma once
 #include "cwlt_common.h"
 
 namespace cwlt {
 
-// Two elements at a time on the packed-f32 VALU ops (v_pk_mul_f32 / v_pk_fma_f32: one instruction, two lanes of
-// arithmetic); only |x|, v_rcp, v_exp and the sign transfer stay per element.  Same A&S 7.1.26 formula.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ void gelu_parts2(f32x2 x, f32x2& cdf, f32x2& pdf) {
-    f32x2 u;
-    u[0] = fabsf(x[0]);
-    u[1] = fabsf(x[1]);
-    u = u * 0.70710678118654752440f;
-    const f32x2 den = u * 0.3275911f + 1.0f;
-    f32x2 t;
-    t[0] = __builtin_amdgcn_rcpf(den[0]);
-    t[1] = __builtin_amdgcn_rcpf(den[1]);
-    const f32x2 arg = (u * -1.44269504088896340736f) * u;          // -u^2 * log2(e)
-    f32x2 e;
-    e[0] = __builtin_amdgcn_exp2f(arg[0]);
-    e[1] = __builtin_amdgcn_exp2f(arg[1]);
-    f32x2 poly = t * 1.061405429f + -1.453152027f;
-    poly = poly * t + 1.421413741f;
-    poly = poly * t + -0.284496736f;
-    poly = poly * t + 0.254829592f;
-    poly = poly * t;
-    const f32x2 erfa = 1.0f - poly * e;
-    f32x2 sg;
-    sg[0] = copysignf(erfa[0], x[0]);
-    sg[1] = copysignf(erfa[1], x[1]);
-    cdf = sg * 0.5f + 0.5f;
-    pdf = e * 0.39894228040143267794f;
+
+constexpr float GELU_Q1 = -3.959011294e-01f, GELU_Q2 = 2.307531891e-01f, GELU_Q3 = -9.244854863e-02f,
+                GELU_Q4 = 2.139916809e-02f, GELU_Q5 = -2.076792892e-03f;
+constexpr float GELU_NEG_HALF_LOG2E = -0.72134752044448170368f;     // exp(-x^2 / 2) = exp2(x * (x * this))
+constexpr float GELU_INV_SQRT_2PI = 0.39894228040143267794f;
+
+// The fit's constants times an output scale s (the dropout keep scale): results then come out already scaled.
+struct GeluK {
+    float c0, c1, c2, c3, c4, c5, pdfc;
+};
+__device__ __forceinline__ GeluK gelu_consts(float s) {
+    GeluK k;
+    k.c0 = 0.5f * s;
+    k.c1 = GELU_Q1 * s;
+    k.c2 = GELU_Q2 * s;
+    k.c3 = GELU_Q3 * s;
+    k.c4 = GELU_Q4 * s;
+    k.c5 = GELU_Q5 * s;
+    k.pdfc = GELU_INV_SQRT_2PI * s;
+    return k;
+}
+// first half: the exponential (kept apart so that a kernel can split the work of one element over two phases)
+__device__ __forceinline__ float gelu_expterm(float x) {
+    return __builtin_amdgcn_exp2f((x * GELU_NEG_HALF_LOG2E) * x);
+}
+// s * Phi(x) and s * (1/2 - e Q(|x|)) >= 0
+__device__ __forceinline__ void gelu_cdf(float x, float e, const GeluK& k, float& cdf, float& us) {
+    const float a = fabsf(x);
+    float q = fmaf(a, k.c5, k.c4);
+    q = fmaf(a, q, k.c3);
+    q = fmaf(a, q, k.c2);
+    q = fmaf(a, q, k.c1);
+    q = fmaf(a, q, k.c0);
+    us = fmaf(-e, q, k.c0);
+    cdf = k.c0 + copysignf(us, x);
+}
+// y = s * gelu(x), dy = s * gelu'(x)
+__device__ __forceinline__ void gelu_scaled(float x, const GeluK& k, float& y, float& dy) {
+    const float e = gelu_expterm(x);
+    float cdf, us;
+    gelu_cdf(x, e, k, cdf, us);
+    y = fmaf(fabsf(x), us, k.c0 * x);
+    dy = fmaf(e * x, k.pdfc, cdf);
 }
 
 }  // namespace cwlt
