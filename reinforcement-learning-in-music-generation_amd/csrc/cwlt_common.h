@@ -155,57 +155,22 @@ __device__ __forceinline__ float wave_max(float v) {
 // keyed by (seed, element_index >> 1); an element is kept iff its 16 bits >= thresh16 = round(p * 65536).
 // The mask is regenerated in backward from the same (seed, index), so no mask tensor is stored, and it
 // does not depend on the vector width a kernel happens to use.
-//
-// Round 3: the per-pair part runs on full-rate integer instructions only (24-bit multiplies, shifts, xors; 7 per
-// pair with the 16-bit shifts as SDWA operands) -- the murmur-style finalizer it replaces spent two v_mul_lo_u32 per
-// pair.  Structure: x = (pair index, low 24 bits) ^ kc;  x ^= x >> 16;  x = lo24(x) * C1;  x ^= (x >> 11) ^ k2;
-// x = lo24(x) * C2;  x ^= x >> 16, where (k1, k2) are two 32-bit keys drawn from the seed by a splitmix64 finalizer
-// (once per thread) and kc = k1 ^ (index bits 24..47) * CA ^ (index bits 48..63) * CB (once per vector of elements).
-// Constants and shifts were picked by a search over mask statistics at the shapes the model uses (keep rate, serial
-// correlation along rows / columns / diagonals, block-sum variance, halves' uniformity, neighbouring seeds); the numpy
-// model of this exact function and those tests live in tests/rng_model.py / tests/test_rng_cpu.py, and
-// tests/test_fullsize_gpu.py checks the kernels' masks against the model bit for bit.
-constexpr uint32_t RNG_C1 = 0xaeee59u, RNG_C2 = 0x899343u, RNG_CA = 0x85ebcbu, RNG_CB = 0xc2b2afu;
-constexpr int RNG_S2 = 11;
-struct RngKey { uint32_t k1, k2; };
-__device__ __forceinline__ RngKey rng_key(uint64_t seed) {
-    uint64_t z = seed + 0x9E3779B97F4A7C15ull;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    z ^= z >> 31;
-    RngKey k;
-    k.k1 = (uint32_t)z;
-    k.k2 = (uint32_t)(z >> 32);
-    return k;
+__device__ __forceinline__ uint32_t hash32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
-__device__ __forceinline__ uint32_t mul24(uint32_t a, uint32_t b) { return __umul24(a, b); }   // v_mul_u32_u24
-// first-round key of every pair whose index shares bits 24..63 with pair_idx
-__device__ __forceinline__ uint32_t rng_block_key(RngKey k, uint64_t pair_idx) {
-    return k.k1 ^ mul24((uint32_t)(pair_idx >> 24), RNG_CA) ^ mul24((uint32_t)(pair_idx >> 48), RNG_CB);
+__device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair_idx) {
+    const uint32_t lo = (uint32_t)pair_idx, hi = (uint32_t)(pair_idx >> 32);
+    const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9u) ^ (hi * 0x85ebca6bu);
+    return hash32(lo * 0x9e3779b1u ^ key);
 }
-// x0 = (low 24 bits of the pair index) ^ block key
-__device__ __forceinline__ uint32_t rng_mix(uint32_t x0, uint32_t k2) {
-    uint32_t x = x0 ^ (x0 >> 16);
-    x = mul24(x, RNG_C1);
-    x = x ^ (x >> RNG_S2) ^ k2;
-    x = mul24(x, RNG_C2);
-    return x ^ (x >> 16);
-}
-__device__ __forceinline__ uint32_t rng_pair(RngKey k, uint64_t pair_idx) {
-    return rng_mix(((uint32_t)pair_idx & 0xffffffu) ^ rng_block_key(k, pair_idx), k.k2);
-}
-__device__ __forceinline__ uint32_t rng_pair(uint64_t seed, uint64_t pair_idx) { return rng_pair(rng_key(seed), pair_idx); }
-// keep flags of N consecutive elements starting at element offset `off`, a multiple of N (N even, N / 2 a power of
-// two: the N / 2 pair indices then differ in their lowest bits only and share one block key); bit j = keep
+// keep flags of N consecutive elements starting at even element offset `off` (N even), bit j = keep
 template <int N>
 __device__ __forceinline__ uint32_t dropout_mask(uint64_t seed, uint64_t off, uint32_t thresh16) {
-    const RngKey k = rng_key(seed);
-    const uint64_t pair0 = off >> 1;
-    const uint32_t x0 = ((uint32_t)pair0 & 0xffffffu) ^ rng_block_key(k, pair0);
     uint32_t m = 0;
 #pragma unroll
     for (int j = 0; j < N; j += 2) {
-        const uint32_t r = rng_mix(x0 ^ (uint32_t)(j >> 1), k.k2);
+        const uint32_t r = rng_pair(seed, (off >> 1) + (j >> 1));
         m |= ((r & 0xffffu) >= thresh16 ? 1u : 0u) << j;
         m |= ((r >> 16) >= thresh16 ? 1u : 0u) << (j + 1);
     }
@@ -215,8 +180,8 @@ __device__ __forceinline__ bool dropout_keep(uint64_t seed, uint64_t idx, uint32
     const uint32_t r = rng_pair(seed, idx >> 1);
     return ((idx & 1) ? (r >> 16) : (r & 0xffffu)) >= thresh16;
 }
-// The same flags as two 16-bit lane masks per hash word (0xffff keep / 0 drop in the half of each element): what a
-// kernel ANDs onto a packed pair of bf16 results.  thresh2 = thresh16 | thresh16 << 16.
+// The keep flags of one hash word as two 16-bit lane masks (0xffff keep / 0 drop in the half of each element): what a
+// kernel ANDs onto a packed pair of bf16 results.  thresh2 = thresh16 | thresh16 << 16 (0: keep everything).
 // Three packed 16-bit instructions per hash word, written as asm: from the elementwise form hipcc builds two 16-bit
 // compares, two v_cndmask_b32 and a v_perm_b32 (the v_cndmask alone measured 13-19 cycles per wave-instruction,
 // tools/probes/valu_rates: profiles/r03_valu_rates.txt).

@@ -43,28 +43,6 @@ typedef __attribute__((address_space(3))) void lds_void;
 //             reaching HBM                                                                                  [FFN forward]
 enum { EPI_MUL = 0, EPI_GELU = 1 };
 
-// Store-phase admission (EXPERIMENT): at most `cap` workgroups of the chip are in their output burst at a time.
-__device__ unsigned int g_store_sem = 0;
-__device__ __forceinline__ void store_sem_acquire(unsigned cap) {
-    // every read of the counter is a returning atomic (memory-side, coherent across the XCDs' L2s): a plain or sc1 load
-    // may be served a stale line by this XCD's L2
-    unsigned v = 0;
-    for (int tries = 0; tries < 4096; ++tries) {
-        if (v < cap) {
-            if (__hip_atomic_compare_exchange_strong(&g_store_sem, &v, v + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
-                                                     __HIP_MEMORY_SCOPE_AGENT))
-                return;
-        } else {
-            __builtin_amdgcn_s_sleep(16);
-            v = __hip_atomic_fetch_add(&g_store_sem, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __hip_atomic_fetch_add(&g_store_sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // bounded wait: go anyway
-}
-__device__ __forceinline__ void store_sem_release() {
-    __hip_atomic_fetch_sub(&g_store_sem, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 template <int EPI, bool NT_STREAMS>
 __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* G, bf16_t* __restrict__ Cout,
@@ -90,7 +68,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     // chip alternates between a phase in which nobody touches HBM (main loops) and one in which everybody stores
     // (epilogues).  A start offset of 0..7 x ~4 us for the first two workgroups of every CU spreads the epilogues over
     // the tile time; later workgroups inherit the spread from the ones they replace.
-    if ((spread & 1) && blockIdx.x < 2 * 256 && gridDim.x > 2 * 256)
+    if (spread && blockIdx.x < 2 * 256 && gridDim.x > 2 * 256)
         for (int i = (blockIdx.x >> 3) & 7; i > 0; --i) __builtin_amdgcn_s_sleep(127);
     const long mrows = min((long)TMR, M - m0);
 
@@ -224,17 +202,9 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
                 *reinterpret_cast<uint2*>(et + row * LDE + c0 + 8 * g + 4 * hf) = __builtin_bit_cast(uint2, p);
             }
         }
-    const unsigned cap = 0;
-    const unsigned jit = (unsigned)spread >> 8;      // EXPERIMENT: random delay of 0 .. jit x 64 clocks in front of the burst
-    if (jit) {
-        unsigned h = blockIdx.x * 2654435761u;
-        h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
-        for (unsigned d = h % (jit + 1); d > 0; d = d > 64 ? d - 64 : 0) __builtin_amdgcn_s_sleep(64);
-    }
     __syncthreads();
     if (EPI == EPI_GELU) {
         if (seed_base) seed += *seed_base;   // device-resident offset: a captured hipGraph draws fresh masks per replay
-        const RngKey rk = rng_key(seed);
         const GeluK gk = gelu_consts(keep_scale);
         const uint32_t thresh2 = thresh | (thresh << 16);
 #pragma unroll
@@ -245,14 +215,20 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
                 float t[8];
                 load8(reinterpret_cast<const bf16_t*>(&hv), t);
                 // element index of (row, column) in the dense (M, N) activation: what cwlt_bias_gelu_dropout_fwd keys
-                // its mask with (the launcher insists on ldc == ldg == N); a multiple of 8, so the four pair indices
-                // share one block key and differ in their two lowest bits (dropout_mask<8>, bit for bit)
+                // its mask with (the launcher insists on ldc == ldg == N).  The keep flags of dropout_mask<8>(seed, off,
+                // thresh), bit for bit: the four pair indices (off >> 1) + 0..3 share their upper word and key (off is a
+                // multiple of 8, so the low word does not carry), and (lo + j) * C = lo * C + j * C -- one 32-bit multiply
+                // instead of four in front of the four hashes; the two 16-bit halves of a hash word become two 16-bit
+                // lane masks that are ANDed onto the packed pair of bf16 results (no compare / select per element).
                 const uint64_t pair0 = ((uint64_t)(m0 + row) * (uint64_t)N + (uint64_t)(n0 + ecol)) >> 1;
-                const uint32_t x0 = ((uint32_t)pair0 & 0xffffffu) ^ rng_block_key(rk, pair0);
+                const uint32_t plo = (uint32_t)pair0, phi = (uint32_t)(pair0 >> 32);
+                const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9u) ^ (phi * 0x85ebca6bu);
+                const uint32_t base = plo * 0x9e3779b1u;
                 u32x4_t r, q;
 #pragma unroll
                 for (int j = 0; j < 8; j += 2) {
-                    const uint32_t keep = keep_lanes16(rng_mix(x0 ^ (uint32_t)(j >> 1), rk.k2), thresh2);
+                    const uint32_t keep =
+                        keep_lanes16(hash32((base + (uint32_t)(j >> 1) * 0x9e3779b1u) ^ key), thresh2);
                     float y0, d0, y1, d1;
                     gelu_scaled(t[j] + b[j], gk, y0, d0);
                     gelu_scaled(t[j + 1] + b[j + 1], gk, y1, d1);
@@ -267,11 +243,6 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
                 else
                     *dst = q;
             }
-        }
-        if (cap) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (tid == 0) store_sem_release();
         }
         return;
     }
@@ -323,20 +294,8 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
 }  // namespace gn
 }  // namespace cwlt
 
-namespace cwlt {
-// gemm_ws.hip: the same two operations as one persistent, wave-specialised workgroup per CU (CWLT_GEMM_WS=0: the
-// kernels of this file)
-bool gemm_ws_enabled();
-int launch_gemm_ws_mul(const void* a, const void* w, const void* g, void* c, float* part, long M, int N, int K, long lda,
-                       long ldw, long ldg, long ldc, bool nt_streams, hipStream_t st);
-int launch_gemm_ws_gelu(const void* a, const void* w, const float* bias, void* g, void* gd, long M, int N, int K,
-                        long lda, long ldw, float p, uint64_t seed, const uint64_t* seed_base, bool nt_streams,
-                        hipStream_t st);
-}  // namespace cwlt
-
 static int spread_starts() {   // CWLT_GEMM_NT_SPREAD=0: all workgroups start at once (A/B switch)
-    static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_SPREAD"); const char* c = getenv("CWLT_GEMM_NT_CAP");
-                              return ((e && e[0] == '0') ? 0 : 1) | ((c ? atoi(c) : 0) << 8); }();
+    static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_SPREAD"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
 }
 
@@ -366,17 +325,11 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
     const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
     const long nblk = mt8 * (N / gn::TNC);
     static const bool nts = [] { const char* e = getenv("CWLT_GEMM_NT"); return !(e && e[0] == '0'); }();   // A/B switch
-    int e;
-    if (gemm_ws_enabled()) {
-        e = launch_gemm_ws_mul(a, w, g, c, part, (long)M, N, K, (long)lda, (long)ldw, (long)ldg, (long)ldc, nts, st);
-    } else {
-        auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_MUL, true> : gn::gemm_nt_mul_kernel<gn::EPI_MUL, false>;
-        hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, st, (const bf16_t*)a, (const bf16_t*)w,
-                           const_cast<bf16_t*>((const bf16_t*)g), (bf16_t*)c, part, (long)M, N, K, (long)lda, (long)ldw,
-                           (long)ldg, (long)ldc, (const float*)nullptr, 0u, 1.0f, (uint64_t)0, (const uint64_t*)nullptr,
-                           spread_starts());
-        e = (int)hipGetLastError();
-    }
+    auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_MUL, true> : gn::gemm_nt_mul_kernel<gn::EPI_MUL, false>;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, st, (const bf16_t*)a, (const bf16_t*)w,
+                       const_cast<bf16_t*>((const bf16_t*)g), (bf16_t*)c, part, (long)M, N, K, (long)lda, (long)ldw,
+                       (long)ldg, (long)ldc, (const float*)nullptr, 0u, 1.0f, (uint64_t)0, (const uint64_t*)nullptr, spread_starts());
+    int e = (int)hipGetLastError();
     if (e || !colsum) return e;
     return launch_colsum_finalize(part, colsum, (int)mtiles, (long)N, N, 1.0f, 0, st);
 }
@@ -402,9 +355,6 @@ int cwlt_gemm_nt_bias_gelu_dropout(const void* a, const void* w, const float* bi
     const long mt8 = (mtiles + 7) / 8 * 8;
     const long nblk = mt8 * (N / gn::TNC);
     static const bool nts = [] { const char* e = getenv("CWLT_GEMM_NT"); return !(e && e[0] == '0'); }();
-    if (gemm_ws_enabled() && N <= 4096)       // the persistent kernel keeps the bias vector in 16 KiB of LDS
-        return launch_gemm_ws_gelu(a, w, bias, g, gd, (long)M, N, K, (long)lda, (long)ldw, p, seed, seed_base, nts,
-                                   (hipStream_t)stream);
     auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_GELU, true> : gn::gemm_nt_mul_kernel<gn::EPI_GELU, false>;
     hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
                        (bf16_t*)gd, (bf16_t*)g, (float*)nullptr, (long)M, N, K, (long)lda, (long)ldw, (long)N, (long)N,

@@ -161,8 +161,8 @@ def test_greedy_ids_bit_exact_vs_oracle(cuda):
 # GEMM weights (same u, once per use).  Independent relative perturbations of rms u accumulate as a random walk:
 # expected norm-wise relative error of a gradient tensor ~ sqrt(n) * u = sqrt(250) * 1.13e-3 = 1.8e-2 (first order:
 # post-LN renormalises every layer, so the perturbations do not grow geometrically).  The test allows 4x that in
-# the L2 norm per tensor -- BF16_GRAD_REL = 7e-2 -- plus, for tensors whose own gradient is tiny next to the model's
-# (cancellation: key-projection biases), the same fraction of the model-wide RMS gradient norm per tensor.
+# the L2 norm per tensor -- BF16_GRAD_REL = 7e-2 -- relative to the tensor's OWN norm, with no additive term (round 2
+# added the model-wide rms norm; measured errors are 1-5 % of the own norm for every tensor, so it was never needed).
 BF16_GRAD_REL = 4 * (2 * (12 * 10 + 5)) ** 0.5 * 2.0 ** -9 / 3 ** 0.5
 
 
@@ -213,15 +213,20 @@ def test_repo_dims_bf16_train_step_grads_match_fp32_oracle(cuda, monkeypatch, sc
         cos = torch.nn.functional.cosine_similarity(p.grad.detach().double().cpu().flatten(),
                                                     pr[name].grad.double().flatten(), dim=0).item()
         rows.append((name, norms[name], d, rel, cos))
-        worst = max(worst, d / (norms[name] + rms_norm))
-        assert d <= BF16_GRAD_REL * (norms[name] + rms_norm), (name, d, norms[name], rms_norm)
+        # The derived bound is relative to the tensor's OWN norm -- for every tensor of this model, down to the
+        # key-projection biases whose true gradient nearly cancels (own norm 5e-6 against an rms tensor norm of 5e-2).  The
+        # floor of 1e-4 of the rms norm only keeps a gradient that is exactly zero in the oracle from dividing by nothing.
+        floor = 1e-4 * rms_norm
+        bound = BF16_GRAD_REL * max(norms[name], floor)
+        worst = max(worst, d / max(norms[name], floor))
+        assert d <= bound, (name, d, norms[name], rms_norm)
     out_dir = os.path.join(os.path.dirname(HERE), "gpurun_out")
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "bf16_grad_errors_%s.txt" % schedule), "w") as f:
             f.write("bound %.4f  rms tensor norm %.4e  losses bf16 %s fp32 %s\n" % (BF16_GRAD_REL, rms_norm, l16, l32))
             for r in rows:
                 f.write("%-70s |g| %.4e  |d| %.4e  rel %.4e  cos %.6f\n" % r)
-    print("worst bf16 gradient error / (own norm + rms norm): %.4f (bound %.4f)" % (worst, BF16_GRAD_REL))
+    print("worst bf16 gradient error / own norm: %.4f (bound %.4f)" % (worst, BF16_GRAD_REL))
 
 
 def test_one_kernel_ffn_forward_equals_gemm_plus_activation_in_the_model(cuda, monkeypatch):

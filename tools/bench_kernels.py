@@ -108,12 +108,6 @@ def bench_ffn1():
           (M, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, (t0 + t1) * 1e3))
     print("       fused cwlt_gemm_nt_bias_gelu_dropout %.1f us (%.0f TF, %.0f GB/s of output)" %
           (t2 * 1e3, fl / t2 / 1e9, M * (512 + 2 * 2048) * 2 / t2 / 1e6))
-    if os.environ.get("CWLT_GEMM_WS_ABLATE"):
-        import ctypes
-        from rlmg_amd import _lib
-        lib = _lib.load()
-        if hasattr(lib, "cwlt_ws_debug_dump"):
-            lib.cwlt_ws_debug_dump()
 
 
 if __name__ == "__main__":
