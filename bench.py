@@ -382,7 +382,13 @@ def main():
                 import bench_ppo
                 pc = bench_ppo.cpu_rollout_baseline(args.ppo_window)
                 out["ppo"]["cpu_baseline"] = pc
-                out["ppo"]["gpu_over_cpu_rollout_only"] = round(out["ppo"]["rollout_only_env_steps_per_s"] / pc["value"], 1)
+                # the CPU figure is ONE rollout per step, the GPU figure args.ppo_rollouts rollouts in lock-step: both batch
+                # sizes are stated next to the ratio, and the ratio per rollout in flight beside it
+                out["ppo"]["gpu_over_cpu_rollout_only"] = {
+                    "ratio": round(out["ppo"]["rollout_only_env_steps_per_s"] / pc["value"], 1),
+                    "gpu_rollouts_per_step": args.ppo_rollouts, "cpu_rollouts_per_step": 1,
+                    "ratio_per_gpu_rollout": round(out["ppo"]["rollout_only_env_steps_per_s"] / args.ppo_rollouts
+                                                   / pc["value"], 2)}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

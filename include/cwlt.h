@@ -47,7 +47,9 @@ int cwlt_abi_version(void);
  * state increment, a prefix pass turns increments into starting states, the scan proper starts every run from its
  * state.  cwlt_scan_segments() is the library's choice (1 once the streams fill the chip; bf16 with row strides % 8
  * == 0 only); seg_ws: cwlt_scan_seg_floats(N, H, segments, backward) floats, NULL when segments == 1.  The backward
- * calls share ONE workspace: dkdv (first) fills it, dq reads it.
+ * calls share ONE workspace: dkdv (first) fills it, dq reads it.  A run owns ceil(chunks / segments) chunks, and every
+ * run must own at least one: (segments - 1) * ceil(chunks / segments) < chunks, chunks = ceil(L / 64) -- e.g. 9 chunks
+ * take 3 segments, not 4 (3 + 3 + 3 + 0); a count that leaves a run empty is CWLT_ERR_ARG.
  *
  * final_state (optional; bf16, row strides % 8 == 0, segments == 1): cwlt_scan_final_state_floats(N, H) floats that
  * receive, per (sequence, head), the scan's state after the last token -- sum_j phi(k_j) v_j^T transposed (64 x 64 f32)

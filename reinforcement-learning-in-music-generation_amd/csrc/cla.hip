@@ -497,6 +497,16 @@ static bool bad_ld(long ld, int H) { return ld < (long)H * D || (ld & 3) != 0; }
 
 extern "C" {
 
+/* A sequence of nch = ceil(L / 64) chunks cut into `segments` pieces of cps = ceil(nch / segments) whole chunks: every
+ * piece must own at least one chunk.  A count such as 4 for 9 chunks (cps 3: the fourth piece is empty) would leave that
+ * piece's state increment unwritten and the prefix / suffix pass would add workspace garbage to its neighbours. */
+static int cwlt_segments_ok(int L, int segments) {
+    const int nch = (L + 63) / 64;
+    if (segments < 1 || segments > nch) return 0;
+    const int cps = (nch + segments - 1) / segments;
+    return (long)(segments - 1) * cps < nch;
+}
+
 int cwlt_scan_segments(int N, int H, int L, int dtype) {
     if (dtype != CWLT_BF16 || N <= 0 || H <= 0 || L <= 0) return 1;
     return cwlt::scan_segments(N, H, L);
@@ -523,7 +533,7 @@ int cwlt_causal_linear_fwd(const void* q, const void* k, const void* v, void* ou
     if (N == 0 || L == 0) return CWLT_OK;
     hipStream_t st = (hipStream_t)stream;
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo) & 7) == 0;
-    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || segments > (L + 63) / 64))) return CWLT_ERR_ARG;
+    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || !cwlt_segments_ok(L, segments)))) return CWLT_ERR_ARG;
     if (final_state && (!fast || segments != 1)) return CWLT_ERR_ARG;   // the bf16 whole-sequence kernel writes it
     if (dtype == CWLT_F32) return launch_fwd<float>(q, k, v, out, zinv, N, H, L, ldq, ldk, ldv, ldo, eps, st);
     if (dtype == CWLT_BF16) {
@@ -552,7 +562,7 @@ int cwlt_causal_linear_bwd_dkdv(const void* q, const void* k, const void* v, con
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo | lddo | lddk | lddv) & 7) == 0;
     if (colsum_k && !fast) return CWLT_ERR_ARG;      // fused column sums exist in the bf16 kernels only
     if (dden && !fast) return CWLT_ERR_ARG;          // the dden hand-over too
-    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || segments > (L + 63) / 64))) return CWLT_ERR_ARG;
+    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || !cwlt_segments_ok(L, segments)))) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
         return launch_bwd_dkdv<float>(q, k, v, out, zinv, dout, dk, dv, N, H, L, ldq, ldk, ldv, ldo, lddo, lddk, lddv,
@@ -581,7 +591,7 @@ int cwlt_causal_linear_bwd_dq(const void* q, const void* k, const void* v, const
     const bool fast = dtype == CWLT_BF16 && ((ldq | ldk | ldv | ldo | lddo | lddq) & 7) == 0;
     if (colsum_q && !fast) return CWLT_ERR_ARG;      // fused column sums exist in the bf16 kernels only
     if (dden && !fast) return CWLT_ERR_ARG;
-    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || segments > (L + 63) / 64))) return CWLT_ERR_ARG;
+    if (segments < 1 || (segments > 1 && (!fast || !seg_ws || !cwlt_segments_ok(L, segments)))) return CWLT_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (dtype == CWLT_F32)
         return launch_bwd_dq<float>(q, k, v, out, zinv, dout, dq, N, H, L, ldq, ldk, ldv, ldo, lddo, lddq, st);

@@ -252,15 +252,19 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
     hipStream_t st = (hipStream_t)stream;
     const bool edge = (N1 & 255) || (N2 & 255);
     constexpr int lds_bytes = wg::NSTAGE * 2 * wg::OPB;                 // 128 KiB: above the 64 KiB default limit
-    static const int lds_ok = [] {
+    // the opt-in is per device: remember which devices have it (a process may launch on several)
+    static unsigned long long lds_set = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= 64 || !((lds_set >> dev) & 1ull)) {
         int e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                          lds_bytes);
         if (!e)
             e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        return e;
-    }();
-    if (lds_ok) return lds_ok;
+        if (e) return e;
+        if (dev < 64) lds_set |= 1ull << dev;
+    }
     hipLaunchKernelGGL(edge ? wg::wgrad_kernel<true> : wg::wgrad_kernel<false>,
                        dim3(((N1 + 255) / 256) * ((N2 + 255) / 256) * S), dim3(1024), lds_bytes, st, (const bf16_t*)a,
                        (const bf16_t*)b, part, (long)M, N1, N2, (long)lda, (long)ldb, mslice);

@@ -269,9 +269,16 @@ class GraphedCall:
             torch.cuda.synchronize(dev)
             before = self._storage()
             graph = torch.cuda.CUDAGraph()
+            dump = os.environ.get("CWLT_GRAPH_DEBUG_DUMP")          # directory: write the captured graph's nodes as DOT
+            if dump:
+                graph.enable_debug_mode()
             with torch.cuda.graph(graph), mode():
                 base.add_(_SEED_STEP)
                 out = self.fn(*static)
+            if dump:
+                os.makedirs(dump, exist_ok=True)
+                graph.debug_dump(os.path.join(dump, "graph_%s_%d.dot" % (getattr(self.fn, "__name__", "fn"),
+                                                                         len(self.graphs))))
             if self._storage() != before:
                 raise RuntimeError("GraphedCall(grad=True): parameter / gradient storage changed DURING capture")
         finally:
@@ -446,9 +453,11 @@ def cla_bwd(q, k, v, out, zinv, dout, want_colsum=False, final_state=None):
     code, st = _lib.dtype_code(q.dtype), _lib.stream_ptr()
     fast = q.dtype == torch.bfloat16 and all(x % 8 == 0 for x in (ldq, ldk, ldv, lddo))
     fused = want_colsum and fast
+    if final_state is not None and not fast:
+        # dout arrived as a view whose row stride the bf16 kernels cannot take (a legal autograd input of the public
+        # causal_linear_attention): the final state is simply not used -- the dkdv + dq pair below handles any stride
+        final_state = None
     if final_state is not None:
-        if not fast:
-            raise ValueError("the one-sweep backward needs bf16 tensors with row strides that are multiples of 8")
         cs = torch.empty((3, N, H * D), dtype=torch.float32, device=q.device) if want_colsum else None
         _call("cwlt_causal_linear_bwd_sweep", *common, _lib.dev(final_state), _lib.dev(dqkv[:, :, 0]),
               _lib.dev(dqkv[:, :, 1]), _lib.dev(dqkv[:, :, 2]), *([_lib.dev(cs[i]) for i in range(3)] if want_colsum

@@ -59,6 +59,16 @@ def test_argument_validation_without_gpu(built):
     assert lib.cwlt_scan_segments(512, 8, 1024, 1) == 1 and lib.cwlt_scan_segments(4, 8, 3584, 1) == 14
     assert lib.cwlt_scan_segments(4, 8, 3584, 0) == 1 and lib.cwlt_scan_segments(1, 8, 50, 1) == 1
     assert lib.cwlt_scan_seg_floats(4, 8, 14, 0) == 4 * 8 * 14 * 6 * 3 * 1024 and lib.cwlt_scan_seg_floats(4, 8, 1, 1) == 0
+    # a segment count that leaves trailing segments empty (9 chunks cut 4 ways: 3 + 3 + 3 + 0) is refused by all three
+    # scan entry points before any launch: the prefix / suffix pass would add the empty segment's unwritten workspace
+    L9 = 9 * 64
+    assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, L9, 64, 512, 512, 512, 512, 1e-6, 4, buf, null, 1, null) == 1001
+    assert lib.cwlt_causal_linear_bwd_dkdv(buf, buf, buf, buf, buf, buf, buf, buf, null, null, null, 1, 8, L9, 64,
+                                           512, 512, 512, 512, 512, 512, 512, 4, buf, 1, null) == 1001
+    assert lib.cwlt_causal_linear_bwd_dq(buf, buf, buf, buf, buf, buf, buf, null, buf, 1, 8, L9, 64,
+                                         512, 512, 512, 512, 512, 512, 4, buf, 1, null) == 1001
+    assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, L9, 64, 512, 512, 512, 512, 1e-6, 10, buf, null, 1, null) == 1001
+    # (3 segments of 3 chunks is what cwlt_scan_segments would hand out for such a length; not launched here: no GPU)
     assert lib.cwlt_sample_categorical(buf, (ctypes.c_int * 2)(5, 300), None, None, 2, 1, 305, 0, null, buf, null, 0, null) == 1001
     # generation step: an incomplete model description is refused before any launch
     m = built.DecodeModel()
