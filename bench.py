@@ -65,6 +65,8 @@ def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
         SCAN_BWD: R * (7 * D * s + H * 4),
         "cwlt_add_dropout_layernorm_fwd": R * (4 * D * s + 8),
         "cwlt_add_dropout_layernorm_bwd": R * (5 * D * s + 8),
+        # the out-projection's residual block (K = D): a, x read; s, y written
+        "cwlt_gemm_nt_bias_dropout_add_layernorm": R * (D + 3 * D) * s,
         "cwlt_bias_gelu_dropout_fwd": R * 2 * F * s,
         "cwlt_bias_gelu_dropout_bwd": R * 3 * F * s,
         "cwlt_colsum": R * 3 * D * s,

@@ -178,6 +178,19 @@ int cwlt_gemm_nt_bias_gelu_dropout(const void* a, const void* w, const float* bi
                                    int64_t M, int N, int K, int64_t lda, int64_t ldw, float p,
                                    uint64_t seed, const uint64_t* seed_base, void* stream);
 
+/* The post-LN residual block in a GEMM's epilogue:  s = x + dropout(bf16(a (M, K) . w (N, K)^T) + bias);
+ * y = LayerNorm(s) * gamma + beta;  mean, rstd per row -- `x = norm1(x + dropout(attention.out_projection(.)))` and
+ * `norm2(x + dropout(linear2(.)))` of fast_transformers' post-LN TransformerEncoderLayer reached from
+ * /root/reference/dqn_policy/model.py:128-137,231-232; replaces a GEMM with bf16 output followed by
+ * cwlt_add_dropout_layernorm_fwd (same dropout stream (seed, row * N + column), same statistics, same rounding points;
+ * the bias is added in f32).  The GEMM's output never reaches HBM.  a, w bf16 with row strides lda, ldw (multiples
+ * of 8); x, s, y (M, N) bf16 dense; bias, gamma, beta (N) f32; mean, rstd (M) f32.  N == 512 (a workgroup owns whole
+ * rows), K % 64 == 0, 16-byte aligned pointers, 0 <= p < 1. */
+int cwlt_gemm_nt_bias_dropout_add_layernorm(const void* a, const void* w, const float* bias, const void* x,
+                                            const float* gamma, const float* beta, void* s, void* y, float* mean,
+                                            float* rstd, int64_t M, int N, int K, int64_t lda, int64_t ldw, float eps,
+                                            float p, uint64_t seed, const uint64_t* seed_base, void* stream);
+
 /* ---- positional encoding + dropout --------------------------------------------------------------
  * y = dropout_p(x + pe[r % T]) -- PositionalEncoding.forward, dqn_policy/model.py:90-92.  pe is the
  * registered (max_len, D) f32 buffer; pe == NULL gives plain dropout, which is also this op's

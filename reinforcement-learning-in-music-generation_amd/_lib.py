@@ -60,6 +60,8 @@ _SIGNATURES = {
     "cwlt_gemm_nt_tiles": [_c_i64],
     "cwlt_gemm_nt_mul": [_ptr] * 6 + [_c_i64, _c_int, _c_int] + [_c_i64] * 4 + [_ptr],
     "cwlt_gemm_nt_bias_gelu_dropout": [_ptr] * 5 + [_c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_u64, _ptr, _ptr],
+    "cwlt_gemm_nt_bias_dropout_add_layernorm": [_ptr] * 10 + [_c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_u64,
+                                                _ptr, _ptr],
     "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_embed_splits": [_c_i64],

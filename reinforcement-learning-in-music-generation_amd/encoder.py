@@ -67,9 +67,14 @@ class _EncoderLayerFn(torch.autograd.Function):
                                             final_state=will_backward)
         ctx.fin = fin
         a2 = a.view(R, D)
-        o = torch.addmm(bo_a, a2, wo_a.t())                                # MFMA
-        s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
-        del o
+        if ops.linear_ln_supported(a2, wo_a, x2):
+            # out-projection + bias + dropout + residual + LayerNorm in ONE kernel: the projection's output never
+            # reaches HBM (ops.linear_ln; the bias enters in f32)
+            s1, x1, mean1, rstd1 = ops.linear_ln(a2, wo_a, ops._f32(bo), x2, g1f, be1f, ops.LN_EPS, p, seeds[0])
+        else:
+            o = torch.addmm(bo_a, a2, wo_a.t())                            # MFMA
+            s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
+            del o
         # bf16, when a backward will follow: the activation pass also leaves gd = mask / (1 - p) * gelu'(h + b1) (in place
         # of h); the backward then needs no activation pass at all -- dh = (dy . W2) * gd leaves the input-gradient GEMM's
         # epilogue (ops.gemm_nt_mul).  The forward does the same from its side: linear1, bias, GELU and dropout are ONE
@@ -82,9 +87,12 @@ class _EncoderLayerFn(torch.autograd.Function):
             h = torch.mm(x1, w1_a.t())                                     # (R, F)  MFMA, bias in next kernel
             fused_ffn = fused_ffn and h.is_contiguous()
             g = ops.gelu_fwd(h, b1f, p, seeds[1], gd_inplace=fused_ffn)
-        y = torch.addmm(b2_a, g, w2_a.t())                                 # MFMA
-        s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
-        del y
+        if ops.linear_ln_supported(g, w2_a, x1):
+            s2, out, mean2, rstd2 = ops.linear_ln(g, w2_a, ops._f32(b2), x1, g2f, be2f, ops.LN_EPS, p, seeds[2])
+        else:
+            y = torch.addmm(b2_a, g, w2_a.t())                             # MFMA
+            s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
+            del y
 
         ctx.save_for_backward(x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2, g1f, g2f, b1f)
         # The weight copies may be the encoder's persistent shadow buffers, which a LATER forward refreshes in place

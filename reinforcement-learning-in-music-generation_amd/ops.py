@@ -633,6 +633,41 @@ def ffn1_gelu_dropout(x, w, bias, p=0.0, seed=0):
     return g, gd
 
 
+# rows from which the one-kernel residual block is used (128-row tiles, one workgroup per CU: below ~2 tiles per CU the
+# hipBLASLt GEMM + LayerNorm kernel pair fills the chip better)
+LINEAR_LN_MIN_ROWS = int(os.environ.get("CWLT_LINEAR_LN_MIN_ROWS", 65536))
+# ... and the reduction lengths: at K = 512 (the out-projection) the one-kernel form takes 0.61 ms against 0.36 + 0.44
+# for the pair at R = 524 288; at K = 2048 (linear2) its serial epilogue (one workgroup per CU: nothing runs beside
+# it) costs more than the pair's extra stream, 1.43 against 0.96 + 0.42 ms (profiles/r03_linear_ln_microbench.txt)
+LINEAR_LN_MAX_K = int(os.environ.get("CWLT_LINEAR_LN_MAX_K", 1024))
+FUSED_LINEAR_LN = os.environ.get("CWLT_FUSED_LINEAR_LN", "1") != "0"
+
+
+def linear_ln_supported(a, w, x):
+    return (FUSED_LINEAR_LN and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and x is not None
+            and x.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2 and w.shape[0] == 512
+            and a.shape[1] == w.shape[1] and a.shape[1] % 64 == 0 and x.shape == (a.shape[0], 512) and x.is_contiguous()
+            and a.shape[0] >= LINEAR_LN_MIN_ROWS and a.shape[1] <= LINEAR_LN_MAX_K
+            and all(t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in (a, w)))
+
+
+def linear_ln(a, w, bias, x, gamma, beta, eps=LN_EPS, p=0.0, seed=0):
+    """s = x + dropout(a @ w.T + bias); y = LayerNorm(s) in ONE kernel (the GEMM's epilogue): what `torch.addmm` +
+    `ln_fwd` produce without the projection's output ever reaching HBM.  a (M, K), w (512, K), x (M, 512) bf16;
+    bias, gamma, beta (512) f32 -> s, y (M, 512) bf16, mean, rstd (M) f32."""
+    _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    s = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    y = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    mean = torch.empty(M, dtype=torch.float32, device=a.device)
+    rstd = torch.empty(M, dtype=torch.float32, device=a.device)
+    _call("cwlt_gemm_nt_bias_dropout_add_layernorm", _lib.dev(a, "a"), _lib.dev(w, "w"), _lib.dev(bias), _lib.dev(x, "x"),
+          _lib.dev(gamma), _lib.dev(beta), _lib.dev(s), _lib.dev(y), _lib.dev(mean), _lib.dev(rstd), M, N, K, a.stride(0),
+          w.stride(0), float(eps), float(p), int(seed), _seed_base(), _lib.stream_ptr(), work=2.0 * M * N * K)
+    return s, y, mean, rstd
+
+
 def gelu_bwd(dg, h, bias, p=0.0, seed=0, want_dbias=True):
     lib = _lib.load()
     rows, F = h.shape

@@ -110,7 +110,33 @@ def bench_ffn1():
           (t2 * 1e3, fl / t2 / 1e9, M * (512 + 2 * 2048) * 2 / t2 / 1e6))
 
 
+def bench_linear_ln():
+    """Residual block: hipBLASLt GEMM (bf16 out, bias) + cwlt_add_dropout_layernorm_fwd   vs   cwlt_gemm_nt_bias_dropout_add_layernorm."""
+    dev = torch.device("cuda:0")
+    M = int(sys.argv[2]) if len(sys.argv) > 2 else 524288
+    for K in (512, 2048):
+        a = torch.randn(M, K, device=dev).bfloat16()
+        w = (torch.randn(512, K, device=dev) * 0.05).bfloat16()
+        b = torch.randn(512, device=dev) * 0.1
+        bb = b.bfloat16()
+        x = torch.randn(M, 512, device=dev).bfloat16()
+        gm, bt = torch.randn(512, device=dev), torch.randn(512, device=dev)
+        t0 = timeit(lambda: torch.addmm(bb, a, w.t()))
+        o = torch.addmm(bb, a, w.t())
+        t1 = timeit(lambda: ops.ln_fwd(x, o, gm, bt, p=0.1, seed=5))
+        t2 = timeit(lambda: ops.linear_ln(a, w, b, x, gm, bt, p=0.1, seed=5))
+        fl = 2.0 * M * 512 * K
+        by = M * (K + 3 * 512) * 2
+        print("M=%d K=%d  unfused: addmm %.1f us (%.0f TF) + ln_fwd %.1f us = %.1f us   fused %.1f us (%.0f TF, %.0f GB/s algorithmic)"
+              % (M, K, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, (t0 + t1) * 1e3, t2 * 1e3, fl / t2 / 1e9, by / t2 / 1e6))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "linln":
+        from rlmg_amd import gemm_tuning
+        gemm_tuning.enable()
+        bench_linear_ln()
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "ffn1":
         from rlmg_amd import gemm_tuning
         gemm_tuning.enable()
