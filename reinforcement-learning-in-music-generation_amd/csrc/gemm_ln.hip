@@ -102,21 +102,21 @@ __global__ __launch_bounds__(1024) void gemm_ln_kernel(
     const int of0 = l31 * 64 + ((hf ^ swz) << 4), of1 = l31 * 64 + (((2 + hf) ^ swz) << 4);
     const int oa = (64 * wm) * 64, ow = TMR * 64 + (64 * wn) * 64;      // wave tile bases; + 32 rows = + 2048 bytes
 #define GL_FRAG(p) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(p))
-#define GL_COMPUTE(stage)                                                                     \
-    {                                                                                         \
-        const char* sb = lds + (stage) * STG;                                                 \
-        const bf16x8 w00 = GL_FRAG(sb + ow + of0), w01 = GL_FRAG(sb + ow + 2048 + of0);       \
-        const bf16x8 x00 = GL_FRAG(sb + oa + of0), x01 = GL_FRAG(sb + oa + 2048 + of0);       \
-        const bf16x8 w10 = GL_FRAG(sb + ow + of1), w11 = GL_FRAG(sb + ow + 2048 + of1);       \
-        const bf16x8 x10 = GL_FRAG(sb + oa + of1), x11 = GL_FRAG(sb + oa + 2048 + of1);       \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w00, x00, acc[0][0], 0, 0, 0);    \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w01, x00, acc[0][1], 0, 0, 0);    \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w00, x01, acc[1][0], 0, 0, 0);    \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w01, x01, acc[1][1], 0, 0, 0);    \
-        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w10, x10, acc[0][0], 0, 0, 0);    \
-        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x10, acc[0][1], 0, 0, 0);    \
-        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w10, x11, acc[1][0], 0, 0, 0);    \
-        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x11, acc[1][1], 0, 0, 0);    \
+    // fragments of one k16 half of a stage: two 32-row blocks of the wave's W rows, two of its a rows
+#define GL_READ(F, stage, ofh)                                            \
+    {                                                                     \
+        const char* sb = lds + (stage) * STG;                             \
+        F[0] = GL_FRAG(sb + ow + (ofh));                                  \
+        F[1] = GL_FRAG(sb + ow + 2048 + (ofh));                           \
+        F[2] = GL_FRAG(sb + oa + (ofh));                                  \
+        F[3] = GL_FRAG(sb + oa + 2048 + (ofh));                           \
+    }
+#define GL_MFMA(F)                                                                          \
+    {                                                                                       \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0], F[2], acc[0][0], 0, 0, 0); \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1], F[2], acc[0][1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[0], F[3], acc[1][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(F[1], F[3], acc[1][1], 0, 0, 0); \
     }
 
     f32x16 acc[2][2];   // [row half i][column half j]: registers = columns (n), lanes = rows (m)
@@ -127,31 +127,68 @@ __global__ __launch_bounds__(1024) void gemm_ln_kernel(
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Ring of 3 stages, DMA two steps ahead, ONE barrier per step (gemm_nt.hip).  A wave leaves its OWN pieces of the
-    // younger step in flight: 3 for waves 0-7 (one a-piece + two w-pieces), 2 for waves 8-15.
+    // Ring of 3 stages, DMA THREE steps ahead, one barrier per step -- placed in the MIDDLE of a step's MFMAs, with the
+    // fragment reads one k16 half ahead of the MFMAs that use them:
+    //   read half 1 of step s | MFMA half 0 of step s | wait: own pieces of step s + 1 landed, own reads of stage s done |
+    //   barrier | DMA step s + 3 into the stage step s used | read half 0 of step s + 1 | MFMA half 1 of step s
+    // so every MFMA group finds its operands in registers, and the LDS reads, the DMA issue and the barrier wait of a
+    // wave fall under MFMAs already queued.  Worth 1-3 % here (0.597 -> 0.589 ms at K = 512): the step is not paced by
+    // fragment latency but by the operand pieces themselves -- 40 KiB per step from L2 through the CU's one
+    // vector-memory queue, ~1 us per step against 0.49 us of MFMA work; issuing the pieces after the
+    // second MFMA group instead of behind the barrier is slower (0.62 ms).
+    // A wave leaves its OWN pieces of the youngest step in flight at the wait: 3 for waves 0-7, 2 for waves 8-15.
     const int nstep = K / BK;                         // K is a multiple of 64 (launcher): nstep >= 2
+    bf16x8 F0[4], F1[4];
     GL_DMA(0, 0);
     GL_DMA(1, 1);
+    if (nstep > 2) GL_DMA(2, 2);
+    if (nstep > 2) {
+        if (w < 8)
+            asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+        if (w < 8)
+            asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    GL_READ(F0, 0, of0);
+    int st = 0;                                       // s % NSTAGE
     for (int s = 0; s < nstep; ++s) {
-        if (s + 1 < nstep) {
-            if (w < 8)
-                asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else
-                asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();
+        const int st1 = st == NSTAGE - 1 ? 0 : st + 1;
+        GL_READ(F1, st, of1);
         __builtin_amdgcn_sched_barrier(0);
-        const int st = s % NSTAGE;
-        if (s + 2 < nstep) GL_DMA((s + 2) % NSTAGE, s + 2);
-        GL_COMPUTE(st);
+        GL_MFMA(F0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (s + 1 < nstep) {
+            // own pieces of step s + 1 have landed (the pieces of step s + 2, issued a step ago, may still fly), and every
+            // fragment read this wave made of stage `st` has returned
+            if (s + 2 < nstep) {
+                if (w < 8)
+                    asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)" ::: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (s + 3 < nstep) GL_DMA(st, s + 3);
+            GL_READ(F0, st1, of0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        GL_MFMA(F1);
+        __builtin_amdgcn_sched_barrier(0);
+        st = st1;
     }
 #undef GL_DMA
 #undef GL_DMA_A
 #undef GL_DMA_W
 #undef GL_FRAG
-#undef GL_COMPUTE
+#undef GL_READ
+#undef GL_MFMA
 
     // ---- epilogue.  The tile leaves the accumulators as bf16 through LDS (the ring is done with) ...
     __syncthreads();
