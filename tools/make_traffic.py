@@ -20,7 +20,7 @@ ENTRY = [("cla_fwd_bf16_kernel", "cwlt_causal_linear_fwd"), ("cla_bwd_sweep_bf16
          ("bias_gelu_dropout_bwd_kernel", "cwlt_bias_gelu_dropout_bwd"), ("wgrad_kernel", "cwlt_wgrad_bf16"),
          ("wgrad_reduce_kernel", "cwlt_wgrad_bf16"), ("cw_embed_bwd", "cwlt_cw_embed_bwd"), ("cw_embed_fwd", "cwlt_cw_embed_fwd"),
          ("heads_fwd", "cwlt_heads_fwd"), ("heads_ce_bwd", "cwlt_heads_ce_bwd"), ("posenc_dropout_kernel", "cwlt_posenc_dropout"),
-         ("gemm_nt_mul_kernel<1", "cwlt_gemm_nt_bias_gelu_dropout"), ("gemm_nt_mul_kernel", "cwlt_gemm_nt_mul")]
+         ("gemm_ln_kernel", "cwlt_gemm_nt_bias_dropout_add_layernorm"), ("gemm_nt_mul_kernel<1", "cwlt_gemm_nt_bias_gelu_dropout"), ("gemm_nt_mul_kernel", "cwlt_gemm_nt_mul")]
 MAIN = {"cwlt_wgrad_bf16": "wgrad_kernel"}      # launches counted by the main kernel of multi-kernel entry points
 
 
