@@ -3,8 +3,9 @@ chain of the op they replace, evaluated on the SAME bf16-rounded inputs.
 
 Tolerances (stated here once, used below):
   * a tensor the kernel stores in bf16 carries one round-to-nearest of the f32 result: |err| <= 2^-9 |ref|; the f32
-    arithmetic in front of it (LayerNorm statistics, erf approximation with |err| <= 1.5e-7, exp/log) is orders of
-    magnitude below that, so BF16_TOL = 2^-7 * max(1, max|ref|), the bound test_cla_bf16_io uses, leaves 4x slack;
+    arithmetic in front of it (LayerNorm statistics, exp/log: orders of magnitude below; the bf16 GELU's
+    Phi(-|x|) = e^{-x^2/2} Q(|x|) form, |err| <= 1.5e-4 absolute for value and derivative: a fiftieth of the bound) stays
+    below that, so BF16_TOL = 2^-7 * max(1, max|ref|), the bound test_cla_bf16_io uses, leaves 4x slack;
   * f32 reductions over rows of exactly-representable bf16 operands (dgamma, dbeta, bias sums, embedding-table
     gradients) see only f32 accumulation error: SUM_TOL = 1e-3 * max(1, max|ref|) for up to 10^4 rows.
 """
@@ -82,7 +83,7 @@ def test_add_dropout_layernorm_bf16_fwd_bwd(cuda, rows, D, residual, p):
 @pytest.mark.parametrize("rows,Fdim", [(3, 2048), (100, 2048), (17, 512), (4096, 2048)])
 @pytest.mark.parametrize("p", [0.0, 0.1])
 def test_bias_gelu_dropout_bf16_fwd_bwd(cuda, rows, Fdim, p):
-    """bf16 path = Abramowitz-Stegun erf on packed f32 (a different function from the f32 path's erff)."""
+    """bf16 path = csrc/cwlt_gelu.h (one exponential, degree-5 polynomial: a different function from the f32 path's erff)."""
     g = torch.Generator().manual_seed(rows)
     h = _bf(torch.randn(rows, Fdim, generator=g) * 2)
     bias = torch.randn(Fdim, generator=g)
