@@ -226,8 +226,13 @@ def main():
     dev = torch.device("cuda", local)
     if args.tune_gemms:
         gemm_tuning.tune(os.path.join(ROOT, "gpurun_out", "gemm_gfx950.csv"))
-    else:
+    elif args.rollouts * args.window >= 16384:
         gemm_tuning.enable()
+    else:
+        # launch-bound shapes (the reference's own 1 rollout x window 50): the table holds no entry for them and
+        # TunableOp's per-call lookup costs ~3 us of host time on each of ~280 GEMM calls of an update that is
+        # host-bound (tools/profile_host_update.py: 25.2 -> 22.3 ms per DQN.update without it)
+        log("tuned GEMM table not loaded: %d token rows per pass are launch-bound" % (args.rollouts * args.window))
     R, W, E = args.rollouts, args.window, args.episodes
     res = run(R, W, E, args.ppo_steps, args.iters, args.warmup, args.dtype, args.group, rank, world, dev)
     if rank == 0:
