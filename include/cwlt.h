@@ -142,6 +142,9 @@ int cwlt_colsum(const void* x, float* part, float* out, int64_t rows, int ncols,
 /* ---- FFN activation: g = dropout_p(gelu(h + bias)) ----------------------------------------------
  * Replaces `self.dropout(self.activation(self.linear1(y)))` (activation='gelu' = exact erf,
  * dqn_policy/model.py:134) with the Linear run bias-free.  bias may be NULL.  F % 8 == 0.
+ * f32 tensors: libm erff / expf (the parity path).  bf16 tensors: Phi(-|x|) = exp(-x^2 / 2) * Q(|x|) with a degree-5
+ * minimax Q -- value and derivative within 1.5e-4 (absolute) of the exact-erf forms, under the 2^-9 relative rounding of
+ * a bf16 result; the GEMM-epilogue forms below use the same function, bit for bit.
  * gd (rows, F), may be NULL: also write the backward's factor gd = mask * 1/(1-p) * gelu'(h + bias), so that
  * dh = dg * gd is one multiply in the epilogue of the GEMM that produces dg (cwlt_gemm_nt_mul).  gd may be h itself
  * (in place: h is then consumed). */
@@ -169,7 +172,8 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
 /* ---- FFN forward: linear1 + bias + GELU + dropout in the GEMM's epilogue ------------------------
  * x = bf16(a (M, K) . w (N, K)^T) + bias (N, f32);  g = dropout_p(gelu(x)),  gd = mask * 1/(1-p) * gelu'(x):
  * `self.dropout(self.activation(self.linear1(y)))` of fast_transformers' TransformerEncoderLayer
- * (dqn_policy/model.py:128-137, activation='gelu' = exact erf) together with the factor cwlt_gemm_nt_mul multiplies the
+ * (dqn_policy/model.py:128-137, activation='gelu' = exact erf; evaluated as cwlt_bias_gelu_dropout_fwd evaluates it for
+ * bf16 tensors) together with the factor cwlt_gemm_nt_mul multiplies the
  * upstream gradient with -- what a plain GEMM followed by cwlt_bias_gelu_dropout_fwd(gd) produces (same arithmetic,
  * the pre-activation rounded to bf16 as the GEMM's output would be, same dropout stream keyed by (seed, element
  * index)), without the (M, N) pre-activation's write and read.  w = linear1.weight as stored, (N, K) row-major.
