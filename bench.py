@@ -236,10 +236,14 @@ def ppo_report(args, ppo, world):
             "replica_spread": ppo["replica_spread"], "dominant_kernel": dom,
             "config": {"workload": "ppo_train iteration (ppo_policy/ppo_train.py:460-506): %d rollouts/GPU x window %d, "
                                    "EPISODES 30, PPO_STEPS %d, actor/critic 512/12/8, reward Longformer 512/12/8 w=512; "
-                                   "env-step = actor greedy fwd + critic value + reward model + buffer write; "
+                                   "env-step = actor greedy fwd + critic value + reward model + buffer write; update: "
+                                   "select_udpate's actor pass on each rollout's last state only -- the one whose rows "
+                                   "the reference returns (ppo_train.py:346; CWLT_PPO_SELECT_ALL=1 runs all 30) --, "
+                                   "CE pass, critic pass, both backwards, two Adam steps; "
                                    "1 warm-up + 1 timed iteration" % (R, W, args.ppo_steps),
                        "rollouts_per_gpu": R, "window": W, "episodes": 30, "ppo_steps": args.ppo_steps,
-                       "update_group": 8, "hipgraph_rollout": ppo["hipgraph_rollout"]}}
+                       "update_group": 8, "hipgraph_rollout": ppo["hipgraph_rollout"],
+                       "select_pass": ppo.get("select_pass", "last-state")}}
 
 
 def main():

@@ -10,7 +10,8 @@ one rollout to R rollouts per GPU run in lock-step:
   rollout phase, EPISODES steps:  actor greedy forward on (R, W, 6) -> action / log-prob rows (reference
       indexing incl. its quirks) -> next state = first half of the old window + the W/2 action tokens ->
       critic value -> reward model (Longformer, band attention) -> GPU-resident buffer write
-  update phase, PPO_STEPS inner steps: per rollout, `select_udpate` on its (EPISODES, W, 6) states, ratio-clip
+  update phase, PPO_STEPS inner steps: per rollout, `select_udpate` on its (EPISODES, W, 6) states (the actor pass on
+      the last state only: the one whose rows the reference returns, ppo_train.py:346; the critic on all), ratio-clip
       surrogate + CE vs the expert windows, critic MSE; gradients accumulated over the R rollouts (--group of
       them stacked per network pass), one Adam step per net per inner step (data-parallel all-reduce across
       GPUs when N > 1).
@@ -147,7 +148,8 @@ def run(rollouts=64, window=1024, episodes=30, ppo_steps=10, iters=1, warmup=1, 
     steps = world * R * E * iters
     return {"env_steps_per_s": steps / dt, "rollout_only_env_steps_per_s": steps / t_roll,
             "ms_per_iteration": 1e3 * dt / iters, "replica_spread": replica_spread, "kernel_times": kernel_times,
-            "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "tokens_per_update_pass": E * W * min(G, R)}
+            "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "tokens_per_update_pass": E * W * min(G, R),
+            "select_pass": "all-states" if P.SELECT_ALL_STATES else "last-state"}
 
 
 def cpu_rollout_baseline(window=1024, seconds_budget=20.0):
@@ -245,6 +247,7 @@ def main():
             "config": {"workload": "ppo_train iteration: %d rollouts/GPU x window %d, EPISODES %d, PPO_STEPS %d, "
                                    "actor/critic 512/12/8, reward Longformer 512/12/8 w=512" % (R, W, E, args.ppo_steps),
                        "hipgraph_rollout": res["hipgraph_rollout"], "update_group": max(1, args.group),
+                       "select_pass": res["select_pass"],
                        "rollouts_per_gpu": R, "window": W, "episodes": E, "ppo_steps": args.ppo_steps,
                        "parallelism": "dp%d" % world}}
         if args.cpu_baseline and world == 1:

@@ -36,6 +36,9 @@ EPSILON = 0.9
 GAMMA = 0.95
 PPO_STEPS = 10
 PPO_CLIP = 0.2
+# CWLT_PPO_SELECT_ALL=1: `select_udpate` runs the actor on every state of the batch, as the reference does, although
+# only the last one's rows are used (see PPO.select_udpate)
+SELECT_ALL_STATES = os.environ.get("CWLT_PPO_SELECT_ALL", "0") == "1"
 DISCOUNT_FACTOR = 0.99
 
 NUM_SONGS = int(os.environ.get("CWLT_NUM_SONGS", 1000))
@@ -131,11 +134,22 @@ class PPO(object):
         return tuple(o.clone() for o in self._graph_step(state_x, reward_mask.float()))
 
     def select_udpate(self, state_x):
-        """ppo_train.py:293-346: the greedy rows / log-probs of the LAST batch element + critic values."""
+        """ppo_train.py:293-346: the greedy rows / log-probs of the LAST batch element + critic values.
+        The reference runs the actor on all B states, builds rows and log-probs for every one of them in a Python loop
+        and returns the loop variables of the last iteration (:346): the other B - 1 elements' actor outputs reach
+        nothing -- no return value, no loss, no gradient.  Sequences do not interact in the network (attention and
+        LayerNorm are per sequence / per row), so the actor is run on the last state only: same action rows, same
+        log-probs, same gradients, 1 / B of the pass (SELECT_ALL_STATES / CWLT_PPO_SELECT_ALL=1 runs all B, the
+        literal form; tests/test_ppo_configs_gpu.py compares the two).  The critic's values are needed for all B."""
         net = self.actor_net
-        logits = net.fused_logits(net.forward_hidden(state_x))                  # (B*T, W)
         B, T = state_x.shape[0], state_x.shape[1]
-        rows = (B - 1) * T + (T - 1 - torch.arange(N_ACTIONS, device=logits.device))
+        back = torch.arange(N_ACTIONS, device=state_x.device)
+        if SELECT_ALL_STATES:
+            logits = net.fused_logits(net.forward_hidden(state_x))              # (B*T, W)
+            rows = (B - 1) * T + (T - 1 - back)
+        else:
+            logits = net.fused_logits(net.forward_hidden(state_x[B - 1:]))      # (T, W): the state whose rows are used
+            rows = T - 1 - back
         logp, action = rl_ops.logp_argmax(logits.float().index_select(0, rows), self.n_class)
         value_state = self.critic_net.value_produce(state_x)
         return action, logp, value_state
@@ -179,9 +193,14 @@ class PPO(object):
         for r0 in range(0, R, group):
             k = min(group, R - r0)
             st = states[:, r0:r0 + k].transpose(0, 1).reshape(k * E, W, 6)              # rollout-major
-            logits = actor.fused_logits(actor.forward_hidden(st))                         # select_udpate pass
+            if SELECT_ALL_STATES:
+                logits = actor.fused_logits(actor.forward_hidden(st))                     # select_udpate pass, literal
+                rows = (((torch.arange(k, device=dev) + 1) * E - 1) * W + (W - 1))[:, None] - back[None, :]
+            else:
+                # select_udpate pass on each rollout's LAST state only: the only one whose rows it returns (see there)
+                logits = actor.fused_logits(actor.forward_hidden(states[E - 1, r0:r0 + k]))
+                rows = (torch.arange(k, device=dev) * W + (W - 1))[:, None] - back[None, :]
             value_pred = critic.value_produce(st).view(k, E, 1)
-            rows = (((torch.arange(k, device=dev) + 1) * E - 1) * W + (W - 1))[:, None] - back[None, :]
             logp_all, _ = rl_ops.logp_argmax(logits.index_select(0, rows.reshape(-1)).float(), self.n_class)
             logp_all = logp_all.view(k, NA, 6)
             tgt = expert[r0:r0 + k, :E + W].unfold(1, W, 1)[:, :E].permute(0, 1, 3, 2).reshape(k * E, W, 6)

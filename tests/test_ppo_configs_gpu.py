@@ -200,6 +200,40 @@ def test_ppo_update_rollouts_grouping_at_config_shapes(cuda, ppo_at_window, monk
     assert worst < 5e-5 * max(1.0, scale), (worst, scale)
 
 
+def test_select_pass_on_the_last_state_only_equals_the_literal_pass_over_all_states(cuda, ppo_at_window, monkeypatch):
+    """`select_udpate` returns the rows of the LAST batch element only (ppo_train.py:346), so the product runs the actor on
+    that state alone; with SELECT_ALL_STATES the actor sees all E states, as in the reference.  Same action rows, same
+    log-probs, same critic values, and -- through `update_rollouts` -- the same gradients of both networks."""
+    W, E = 1024, 30
+    agent, P = ppo_at_window(W)
+    NA, R = W // 2, 3
+    g = torch.Generator().manual_seed(77)
+    states = _tokens(g, (E, R, W)).to(cuda)
+    expert = _tokens(g, (R, E + W + 3)).to(cuda)
+    mask = torch.ones(R, E + W + 3).to(cuda)
+    old_int = (-3 * torch.rand(E, R, NA, 6, generator=g)).long().to(cuda)
+    advs = [torch.randn(E, generator=g).to(cuda) for _ in range(R)]
+    rets = [torch.randn(E, generator=g).to(cuda) for _ in range(R)]
+    for opt in (agent.actor_optim, agent.critic_optim):                # keep the gradients, skip the step
+        monkeypatch.setattr(opt, "step", lambda *a, **k: None)
+    out = {}
+    for literal in (False, True):
+        monkeypatch.setattr(P, "SELECT_ALL_STATES", literal)
+        with torch.no_grad():
+            a, lp, v = agent.select_udpate(states[:, 1])
+        agent.update_rollouts(states, old_int, advs, rets, expert, mask, group=8)
+        out[literal] = (a.clone(), lp.clone(), v.clone(),
+                        [p.grad.detach().clone() for net in (agent.actor_net, agent.critic_net)
+                         for p in net.parameters() if p.grad is not None])
+    (a0, l0, v0, g0), (a1, l1, v1, g1) = out[False], out[True]
+    assert torch.equal(a0, a1) and a0.shape == (NA, 6)
+    assert (l0 - l1).abs().max().item() < 1e-5 and (v0 - v1).abs().max().item() < 1e-6
+    scale = max(t.abs().max().item() for t in g1)
+    assert scale > 1e-5
+    worst = max((x - y).abs().max().item() for x, y in zip(g0, g1))
+    assert worst < 5e-5 * max(1.0, scale), (worst, scale)
+
+
 def test_ppo_rollout_step_at_config2_window(cuda, ppo_at_window):
     """One env step of configs[2] (window 1024) for 3 rollouts through PPO.rollout_step (graph replay) == the eager
     device function; next state = first half of the window + the action rows (ppo_train.py:483)."""
