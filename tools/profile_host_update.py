@@ -16,6 +16,9 @@ from rlmg_amd.dqn_policy import IRL_dqn_train as T
 
 if os.environ.get("NO_TUNED") != "1":
     gemm_tuning.enable()
+if os.environ.get("BLAS"):                      # "cublas" = rocBLAS, "cublaslt" = hipBLASLt (the default on this build)
+    torch.backends.cuda.preferred_blas_library(os.environ["BLAS"])
+    print("preferred BLAS library:", torch.backends.cuda.preferred_blas_library())
 n_class = [56, 135, 18, 87, 18, 25]
 with contextlib.redirect_stdout(io.StringIO()):
     agent = T.DQN(n_class, Pretrain=False)
