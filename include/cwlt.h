@@ -371,6 +371,14 @@ int cwlt_sample_categorical(const float* logits, const int* n_class, const float
                             const int64_t* counter, int64_t* tokens, int64_t* song, int64_t song_rows,
                             void* stream);
 
+/* ---- hipGraph hygiene (no counterpart in the reference, which has no graphs; used by the drop-in RL loops' replayed
+ * steps) -------------------------------------------------------------------------------------------
+ * Replace every MEMSET node of a captured, not yet instantiated hipGraph_t by a kernel node writing the same bytes (same
+ * dependencies, same dependents): on ROCm 7.2 a captured hipMemsetAsync replays a wrong fill pattern from the second
+ * replay on, and library code inside a captured step (PyTorch's reduction semaphores, hipBLASLt's split-K workspaces)
+ * issues such memsets.  *replaced (may be NULL): nodes replaced.  Child graphs are not entered.  0 or a hipError_t. */
+int cwlt_graph_replace_memset_nodes(void* graph, int* replaced);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 13
+ABI_VERSION = 14
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -62,6 +62,7 @@ _SIGNATURES = {
     "cwlt_gemm_nt_bias_gelu_dropout": [_ptr] * 5 + [_c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_u64, _ptr, _ptr],
     "cwlt_gemm_nt_bias_dropout_add_layernorm": [_ptr] * 10 + [_c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_u64,
                                                 _ptr, _ptr],
+    "cwlt_graph_replace_memset_nodes": [_ptr, _ptr],
     "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_embed_splits": [_c_i64],
@@ -107,7 +108,8 @@ def load():
     rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
     if not os.path.exists(rt):
         raise ImportError("PyTorch-ROCm's HIP runtime not found at %s" % rt)
-    ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+    global _hip
+    _hip = ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
     lib = ctypes.CDLL(LIB_PATH)
     for name, argtypes in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so is stale
@@ -119,6 +121,43 @@ def load():
         raise ImportError("libcwlt.so ABI version %d, binding expects %d -- rebuild" % (got, ABI_VERSION))
     _lib = lib
     return lib
+
+
+_hip = None
+# hipGraphNodeType (hip_runtime_api.h): the kinds of node a stream capture can record
+GRAPH_NODE_TYPES = {0: "kernel", 1: "memcpy", 2: "memset", 3: "host", 4: "graph", 5: "empty", 6: "wait_event",
+                    7: "event_record"}
+
+
+def graph_node_census(raw_graph):
+    """{node kind: count} of a hipGraph_t (an integer handle, e.g. torch.cuda.CUDAGraph(keep_graph=True)
+    .raw_cuda_graph()), child graphs included.  Used to keep memset nodes out of replayed graphs: a captured
+    hipMemsetAsync replays a wrong fill pattern on ROCm 7.2 (tools/probes/graph_memset_probe.py)."""
+    load()
+    counts = {}
+
+    def walk(g):
+        n = ctypes.c_size_t(0)
+        if _hip.hipGraphGetNodes(ctypes.c_void_p(g), None, ctypes.byref(n)) != 0:
+            raise RuntimeError("hipGraphGetNodes failed")
+        if n.value == 0:
+            return
+        nodes = (ctypes.c_void_p * n.value)()
+        if _hip.hipGraphGetNodes(ctypes.c_void_p(g), nodes, ctypes.byref(n)) != 0:
+            raise RuntimeError("hipGraphGetNodes failed")
+        for node in nodes:
+            t = ctypes.c_int(-1)
+            if _hip.hipGraphNodeGetType(ctypes.c_void_p(node), ctypes.byref(t)) != 0:
+                raise RuntimeError("hipGraphNodeGetType failed")
+            kind = GRAPH_NODE_TYPES.get(t.value, "type%d" % t.value)
+            counts[kind] = counts.get(kind, 0) + 1
+            if t.value == 4:
+                child = ctypes.c_void_p(0)
+                if _hip.hipGraphChildGraphNodeGetGraph(ctypes.c_void_p(node), ctypes.byref(child)) == 0 and child.value:
+                    walk(child.value)
+
+    walk(int(raw_graph))
+    return counts
 
 
 def exported_names():

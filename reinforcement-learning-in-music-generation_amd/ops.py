@@ -235,6 +235,8 @@ class GraphedCall:
     def __init__(self, fn, warmup=2, grad=False, eager_calls=2, params=None):
         self.fn, self.warmup, self.grad, self.eager_calls = fn, warmup, grad, eager_calls
         self.graphs, self.calls = {}, {}
+        self.census = None                                 # node kinds of the last capture (_lib.graph_node_census)
+        self.memsets_replaced = 0
         # grad=True: the parameters the step trains.  Their storage and their .grad storage are baked into the graph
         # as raw addresses; `_storage()` is compared before every replay so that a moved buffer (a dropped / re-made
         # .grad, a re-allocated parameter) raises instead of letting the graph write through a stale address.
@@ -268,17 +270,35 @@ class GraphedCall:
                 torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             before = self._storage()
-            graph = torch.cuda.CUDAGraph()
-            dump = os.environ.get("CWLT_GRAPH_DEBUG_DUMP")          # directory: write the captured graph's nodes as DOT
-            if dump:
-                graph.enable_debug_mode()
+            # keep_graph: the hipGraph_t stays accessible after the capture so that its nodes can be counted; the
+            # executable graph is instantiated by the first replay
+            graph = torch.cuda.CUDAGraph(keep_graph=True)
             with torch.cuda.graph(graph), mode():
                 base.add_(_SEED_STEP)
                 out = self.fn(*static)
-            if dump:
-                os.makedirs(dump, exist_ok=True)
-                graph.debug_dump(os.path.join(dump, "graph_%s_%d.dot" % (getattr(self.fn, "__name__", "fn"),
-                                                                         len(self.graphs))))
+            # A captured hipMemsetAsync replays a WRONG fill pattern on ROCm 7.2 from the second replay on when other work
+            # runs in between (tools/probes/graph_memset_probe.py), and library code inside the step issues such memsets
+            # (PyTorch's reduction semaphores, hipBLASLt's split-K workspaces: tools/diag_memset_sites.py).  Before the
+            # graph is instantiated every memset node is therefore replaced by a fill-kernel node
+            # (cwlt_graph_replace_memset_nodes); `census` records the node kinds before that, `memsets_replaced` how many
+            # were rewritten.  Should any memset node remain (inside a child graph), the capture is never replayed and the
+            # step keeps running eagerly -- the capture itself executed nothing.
+            raw = graph.raw_cuda_graph()
+            self.census = _lib.graph_node_census(raw)
+            self.memsets_replaced = 0
+            if self.census.get("memset", 0):
+                n = ctypes.c_int(0)
+                _lib.check(_lib.load().cwlt_graph_replace_memset_nodes(ctypes.c_void_p(int(raw)), ctypes.byref(n)),
+                           "cwlt_graph_replace_memset_nodes")
+                self.memsets_replaced = n.value
+                left = _lib.graph_node_census(raw).get("memset", 0)
+                if left:
+                    import warnings
+                    warnings.warn("GraphedCall: the captured %s still holds %d memset node(s) after the rewrite (%s); a "
+                                  "replayed hipMemsetAsync is not reliable on this runtime -- running this signature "
+                                  "eagerly instead" % (getattr(self.fn, "__name__", "step"), left, self.census))
+                    graph.reset()
+                    graph = None
             if self._storage() != before:
                 raise RuntimeError("GraphedCall(grad=True): parameter / gradient storage changed DURING capture")
         finally:
@@ -297,6 +317,8 @@ class GraphedCall:
             ent = self.graphs[key] = self._capture(args)
             self._addr[key] = self._storage()
         graph, static, out = ent
+        if graph is None:                                  # a capture that was refused (memset nodes): eager
+            return self.fn(*args)
         if self.params and self._storage() != self._addr[key]:
             raise RuntimeError("GraphedCall(grad=True): parameter / gradient storage moved since the step was "
                                "captured (a .grad was dropped or re-created, or a parameter re-allocated)")

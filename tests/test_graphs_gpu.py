@@ -298,3 +298,46 @@ def test_weight_shadows_follow_the_parameters(cuda, tmp_path, monkeypatch):
         assert torch.equal(g_shadow, net.transformer_encoder.layers[0].linear1.weight.grad)
     finally:
         config.AgentConfig.update(old)
+
+
+def test_captures_are_counted_and_memset_nodes_are_rewritten_as_kernels(cuda):
+    """GraphedCall counts the node kinds of what it captured (hipGraphGetNodes).  A captured hipMemsetAsync replays a wrong
+    fill pattern on ROCm 7.2 from the second replay on (tools/probes/graph_memset_probe.py,
+    profiles/r03_graph_memset_probe.txt), so every memset node is replaced by a fill-kernel node before the graph is
+    instantiated (cwlt_graph_replace_memset_nodes): the replays then write the right bytes."""
+    import ctypes
+    import os
+    from rlmg_amd import _lib
+    x = torch.randn(64, 512, device=cuda).bfloat16()
+    ok = ops.GraphedCall(lambda t: ops.colsum(t).clone())
+    want = x.float().sum(0)
+    for _ in range(3):
+        got = ok(x)
+        assert (got - want).abs().max().item() < 1e-2 * want.abs().max().item()
+    assert ok.census.get("kernel", 0) >= 2 and ok.census.get("memset", 0) == 0 and ok.memsets_replaced == 0
+    # a step that zeroes buffers with hipMemsetAsync (what PyTorch's reductions and hipBLASLt do inside a step): 1-, 2-
+    # and 4-byte patterns, an odd length
+    hip = ctypes.CDLL(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    buf = torch.ones(1 << 20, device=cuda)
+    b16 = torch.ones(1001, device=cuda, dtype=torch.int16)
+    b32 = torch.ones(777, device=cuda, dtype=torch.int32)
+
+    def step(t):
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert hip.hipMemsetAsync(ctypes.c_void_p(buf.data_ptr()), 0, ctypes.c_size_t(buf.numel() * 4), st) == 0
+        assert hip.hipMemsetD16Async(ctypes.c_void_p(b16.data_ptr()), ctypes.c_ushort(0x1234), ctypes.c_size_t(1001), st) == 0
+        assert hip.hipMemsetD32Async(ctypes.c_void_p(b32.data_ptr()), ctypes.c_int(-7), ctypes.c_size_t(777), st) == 0
+        return buf[:4096] + t
+
+    g = ops.GraphedCall(step)
+    t = torch.randn(4096, device=cuda)
+    for _ in range(5):
+        buf.fill_(float("nan"))                          # poison: only a correct fill makes the result finite
+        b16.fill_(-1)
+        b32.fill_(5)
+        torch.mm(torch.randn(2048, 2048, device=cuda), torch.randn(2048, 2048, device=cuda))   # work in between
+        out = g(t).clone()
+        assert torch.equal(out, t) and torch.count_nonzero(buf).item() == 0
+        assert bool((b16 == 0x1234).all()) and bool((b32 == -7).all())
+    assert g.census.get("memset", 0) == 3 and g.memsets_replaced == 3
+    assert _lib.GRAPH_NODE_TYPES[2] == "memset"

@@ -1,16 +1,13 @@
 """What does a captured `DQN.update` bake in?  Captures the update step (repo dims, bf16, batch 30 x window 50) with
-CWLT_TRAIN_GRAPHS=1 and dumps the hipGraph's nodes (CUDAGraph.debug_dump): counts kernel / memset / memcpy nodes and
-lists the memset nodes -- a captured hipMemsetAsync replays with a wrong fill pattern on ROCm 7.2
-(tools/probes/graph_memset_probe.py), so every memset node is a place where a replay can read garbage.
-usage: python tools/diag_graph_nodes.py [tuned|default] [bf16|f32]       (GPU box; captures once, replays nothing)"""
-import collections
-import glob
+CWLT_TRAIN_GRAPHS=1 and prints the node census of the hipGraph (`GraphedCall.census`, from hipGraphGetNodes): kernel /
+memset / memcpy nodes -- a captured hipMemsetAsync replays with a wrong fill pattern on ROCm 7.2
+(tools/probes/graph_memset_probe.py), so every memset node is a place where a replay can read garbage (GraphedCall
+refuses to replay such a capture).  DIAG_REPLAYS=n: n further updates (replays), for a kernel trace under rocprofv3.
+usage: python tools/diag_graph_nodes.py [tuned|default] [bf16|f32]       (GPU box)"""
 import os
-import re
 import sys
 
 os.environ["CWLT_TRAIN_GRAPHS"] = "1"
-os.environ.setdefault("CWLT_GRAPH_DEBUG_DUMP", os.path.join("gpurun_out", "graph_dump"))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch  # noqa: E402
 
@@ -40,15 +37,11 @@ def main():
     for i in range(3 + n_replay):                        # 2 eager calls, the third is captured, then replays
         m, c, t = agent.update(tr, dict(tr), torch.ones(B, 50).cuda(), False, 0)
     torch.cuda.synchronize()
-    files = sorted(glob.glob(os.path.join(os.environ["CWLT_GRAPH_DEBUG_DUMP"], "*.dot")))
-    print("losses of the captured step:", m, c, t, "| dumps:", files)
-    for f in files:
-        txt = open(f).read()
-        kinds = collections.Counter(re.findall(r'label="[^"]*?(KERNEL|MEMSET|MEMCPY|Kernel|Memset|Memcpy|EMPTY|HOST)', txt))
-        print(os.path.basename(f), dict(kinds), "nodes total", txt.count("label="))
-        for line in txt.splitlines():
-            if re.search(r"MEMSET|Memset|memset", line):
-                print("   ", line.strip()[:300])
+    print("losses of the last step:", m, c, t)
+    print("update graph census:", agent._graph_update.census)
+    gc = getattr(agent, "_graph_choose", None)
+    if gc is not None:
+        print("choose_action graph census:", gc.census)
 
 
 if __name__ == "__main__":
