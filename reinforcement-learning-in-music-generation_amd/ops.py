@@ -680,6 +680,8 @@ def linear_ln(a, w, bias, x, gamma, beta, eps=LN_EPS, p=0.0, seed=0):
     _lib.load()
     M, K = a.shape
     N = w.shape[0]
+    if x.shape != (M, N) or not x.is_contiguous() or x.dtype != a.dtype:
+        raise ValueError("linear_ln: the residual must be a dense (%d, %d) tensor of the operands' dtype" % (M, N))
     s = torch.empty((M, N), dtype=a.dtype, device=a.device)
     y = torch.empty((M, N), dtype=a.dtype, device=a.device)
     mean = torch.empty(M, dtype=torch.float32, device=a.device)

@@ -62,8 +62,10 @@ def test_linear_ln_rejects_what_it_cannot_run(cuda):
     x = torch.randn(256, 512, device=cuda).bfloat16()
     f = torch.randn(512, device=cuda)
     w256 = torch.randn(256, 512, device=cuda).bfloat16()
-    with pytest.raises(RuntimeError):
+    with pytest.raises(RuntimeError):                 # N != 512: refused by the C-ABI
         ops.linear_ln(a, w256, f[:256].contiguous(), x[:, :256].contiguous(), f[:256].contiguous(), f[:256].contiguous())
+    with pytest.raises(ValueError):                   # a strided residual view: refused by the wrapper
+        ops.linear_ln(a, w, f, torch.randn(256, 1024, device=cuda).bfloat16()[:, :512], f, f)
     assert not ops.linear_ln_supported(a.float(), w.float(), x.float())
     assert not ops.linear_ln_supported(a, w256, x)
     e = torch.empty(0, 512, device=cuda).bfloat16()
