@@ -206,7 +206,8 @@ int cwlt_posenc_dropout(const void* x, const float* pe, void* y, int64_t rows, i
  * out[r, off_f : off_f+width_f] = table_f[tokens[r, f]] * sqrt(width_f), f = 0..n_attr-1.
  * Replaces Embeddings.forward x6 + torch.cat (dqn_policy/model.py:67-74,206-221;
  * ppo_policy/model.py:69-76,208-223; dqn_policy/AIRL_model.py:34-41,108-115).
- * tables / widths / nrows are HOST arrays (device pointers to f32 tables; widths % 64 == 0). */
+ * tables / widths / nrows are HOST arrays (device pointers to f32 tables; widths % 64 == 0).  out: 16-byte aligned,
+ * row stride ldo a multiple of 8 elements (bf16) / 4 (f32). */
 int cwlt_embed_splits(int64_t rows);
 int cwlt_cw_embed_fwd(const int64_t* tokens, const void* const* tables, const int* widths,
                       const int* nrows, int n_attr, void* out, int64_t rows, int64_t ldo,
