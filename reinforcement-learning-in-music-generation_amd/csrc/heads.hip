@@ -170,6 +170,48 @@ __global__ __launch_bounds__(256) void heads_ce_bwd_kernel(const T* __restrict__
 // are assigned to the 8 half-wave slots in order of decreasing vocabulary so both halves of a wave loop alike.
 // Results that are matrices (probs, dlogits) go back through the LDS tile and leave with coalesced stores.
 // ------------------------------------------------------------------------------------------------
+// The tile kernels walk a row's n_f logits serially in LDS.  Written one element per iteration the loop is a chain of
+// dependent LDS round trips (~100 cycles each: 40 k cycles per 32-row tile at 135 classes); these
+// helpers keep 8 independent reads in flight per step.
+__device__ __forceinline__ float row_max(const float* x, int n) {
+    float mx = -INFINITY;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[j + u];
+        mx = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])), mx));
+    }
+    for (; j < n; ++j) mx = fmaxf(mx, x[j]);
+    return mx;
+}
+// sum_j exp(x_j - mx); STORE: x_j <- exp(x_j - mx)
+template <typename T, bool STORE>
+__device__ __forceinline__ float row_sumexp(float* x, int n, float mx) {
+    float sum = 0.f;
+    int j = 0;
+    for (; j + 8 <= n; j += 8) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = x[j + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = sm_exp<T>(v[u] - mx);
+        if (STORE) {
+#pragma unroll
+            for (int u = 0; u < 8; ++u) x[j + u] = v[u];
+        }
+        // the summation order of the one-by-one loop: bit-identical results
+#pragma unroll
+        for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; j < n; ++j) {
+        const float e = sm_exp<T>(x[j] - mx);
+        if (STORE) x[j] = e;
+        sum += e;
+    }
+    return sum;
+}
+
 constexpr int HT_ROWS = 32;
 
 struct TileOrder {
@@ -217,10 +259,8 @@ __global__ __launch_bounds__(256) void heads_fwd_tile_kernel(const T* __restrict
         __syncthreads();
         if (f >= 0 && r < rows) {
             float* x = xs + row * W1 + off;
-            float mx = -INFINITY;
-            for (int j = 0; j < n; ++j) mx = fmaxf(mx, x[j]);
-            float sum = 0.f;
-            for (int j = 0; j < n; ++j) sum += sm_exp<T>(x[j] - mx);
+            const float mx = row_max(x, n);
+            const float sum = row_sumexp<T, false>(x, n, mx);
             if (target) {
                 long tg = target[r * a.n_attr + f];
                 tg = tg < 0 ? 0 : (tg >= n ? n - 1 : tg);
@@ -230,7 +270,22 @@ __global__ __launch_bounds__(256) void heads_fwd_tile_kernel(const T* __restrict
                 // first index of the largest softmax VALUE (softmax then argmax, as the reference does)
                 float best = -1.f;
                 int bi = 0;
-                for (int j = 0; j < n; ++j) {
+                int j = 0;
+                for (; j + 8 <= n; j += 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = x[j + u];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) v[u] = sm_exp<T>(v[u] - mx) / sum;
+                    if (probs) {
+#pragma unroll
+                        for (int u = 0; u < 8; ++u) x[j + u] = v[u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u)
+                        if (v[u] > best) { best = v[u]; bi = j + u; }
+                }
+                for (; j < n; ++j) {
                     const float p = sm_exp<T>(x[j] - mx) / sum;
                     if (probs) x[j] = p;
                     if (p > best) { best = p; bi = j; }
@@ -279,19 +334,21 @@ __global__ __launch_bounds__(256) void heads_ce_bwd_tile_kernel(const T* __restr
         __syncthreads();
         if (f >= 0 && r < rows) {
             float* x = xs + row * W1 + off;
-            float mx = -INFINITY;
-            for (int j = 0; j < n; ++j) mx = fmaxf(mx, x[j]);
-            float sum = 0.f;
-            for (int j = 0; j < n; ++j) {
-                const float e = sm_exp<T>(x[j] - mx);
-                x[j] = e;
-                sum += e;
-            }
+            const float mx = row_max(x, n);
+            const float sum = row_sumexp<T, true>(x, n, mx);
             long tg = target[r * a.n_attr + f];
             tg = tg < 0 ? 0 : (tg >= n ? n - 1 : tg);
             const float w = wrf ? wrf[r * a.n_attr + f] : (mask ? mask[r] : 1.f) * coef[f];
             const float inv = 1.0f / sum;
-            for (int j = 0; j < n; ++j) x[j] = (x[j] * inv - (j == (int)tg ? 1.f : 0.f)) * w;
+            int j = 0;
+            for (; j + 8 <= n; j += 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = x[j + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) x[j + u] = (v[u] * inv - (j + u == (int)tg ? 1.f : 0.f)) * w;
+            }
+            for (; j < n; ++j) x[j] = (x[j] * inv - (j == (int)tg ? 1.f : 0.f)) * w;
         } else if (f < 0 && slot == CWLT_MAX_ATTR - 1) {
             // the last (always idle when n_attr < 8) slot clears the padding columns of its row
             for (int c = used; c < (int)ld; ++c) xs[row * W1 + c] = 0.f;
