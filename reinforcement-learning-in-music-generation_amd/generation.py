@@ -156,6 +156,7 @@ class DecodeSession:
         self._host_logits = torch.zeros((n, self.width), dtype=torch.float32).pin_memory()
         self.use_graph = ops.GRAPHS_ENABLED if graph is None else bool(graph)
         self._graph, self._out, self._plan = None, None, None
+        self.census = None                                    # node kinds of the captured step (ops.capture_hip_graph)
         self.hidden = None                                  # (n_songs, d_model) device tensor after a step
         self.n_steps = 0
 
@@ -202,10 +203,12 @@ class DecodeSession:
                 self._device_step()
         torch.cuda.current_stream(self.dev).wait_stream(side)
         torch.cuda.synchronize(self.dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g), torch.no_grad():
-            out = self._device_step()
-        self._state.copy_(saved)                              # warm-up and capture ran the step: restore
+        # ops.capture_hip_graph: memset nodes (none in cwlt_decode_step; the module path's torch ops may add some) are
+        # rewritten as kernels before the graph is instantiated; a capture that cannot be made safe is not replayed
+        g, out, self.census, _ = ops.capture_hip_graph(self._device_step, torch.no_grad, "decode step")
+        self._state.copy_(saved)                              # warm-up ran the step: restore
+        if g is None:
+            self.use_graph = False
         self._graph, self._out = g, out
 
     def step(self, ids):
@@ -217,6 +220,7 @@ class DecodeSession:
         if self.use_graph:
             if self._graph is None:
                 self._capture()
+        if self.use_graph:
             self._graph.replay()
             out = self._out
         else:
@@ -272,9 +276,12 @@ class _DeviceLoop:
                 else:
                     if self._graph is None:
                         torch.cuda.synchronize(self.sess.dev)
-                        self._graph = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(self._graph):       # recorded, not executed
+                        self._graph = ops.capture_hip_graph(self._one, torch.no_grad, "decode loop")[0]   # recorded,
+                        if self._graph is None:                                                      # not executed
+                            self.use_graph = False
                             self._one()
+                            self.enqueued += 1
+                            continue
                     self._graph.replay()
                 self.enqueued += 1
         return n

@@ -219,6 +219,39 @@ def graph_adam(params, lr, **kw):
     return torch.optim.Adam(params, lr=lr, **kw)
 
 
+def capture_hip_graph(body, mode=torch.no_grad, name="step"):
+    """Capture `body()` on the current stream into a hipGraph that is safe to replay on this runtime.
+    -> (torch.cuda.CUDAGraph or None, body's result, node census before the rewrite, memset nodes rewritten).
+
+    A captured hipMemsetAsync replays a WRONG fill pattern on ROCm 7.2 from the second replay on when other work runs
+    in between (tools/probes/graph_memset_probe.py), and library code inside a captured step issues such memsets
+    (PyTorch's reduction semaphores, hipBLASLt's split-K workspaces: tools/diag_memset_sites.py).  Before the graph is
+    instantiated every memset node is therefore replaced by a fill-kernel node (cwlt_graph_replace_memset_nodes).
+    keep_graph: the hipGraph_t stays accessible after the capture so that its nodes can be counted and edited; the
+    executable graph is instantiated by the first replay.  Should any memset node remain (inside a child graph), None
+    is returned in place of the graph: the caller must run the step eagerly -- the capture itself executed nothing."""
+    graph = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(graph), mode():
+        out = body()
+    raw = graph.raw_cuda_graph()
+    census = _lib.graph_node_census(raw)
+    replaced = 0
+    if census.get("memset", 0):
+        n = ctypes.c_int(0)
+        _lib.check(_lib.load().cwlt_graph_replace_memset_nodes(ctypes.c_void_p(int(raw)), ctypes.byref(n)),
+                   "cwlt_graph_replace_memset_nodes")
+        replaced = n.value
+        left = _lib.graph_node_census(raw).get("memset", 0)
+        if left:
+            import warnings
+            warnings.warn("capture_hip_graph: the captured %s still holds %d memset node(s) after the rewrite (%s); a "
+                          "replayed hipMemsetAsync is not reliable on this runtime -- running it eagerly instead"
+                          % (name, left, census))
+            graph.reset()
+            graph = None
+    return graph, out, census, replaced
+
+
 class GraphedCall:
     """Run `fn(*tensors)` -- a sync-free function of device tensors -- as ONE hipGraph launch.
 
@@ -270,35 +303,11 @@ class GraphedCall:
                 torch.cuda.current_stream(dev).wait_stream(side)
             torch.cuda.synchronize(dev)
             before = self._storage()
-            # keep_graph: the hipGraph_t stays accessible after the capture so that its nodes can be counted; the
-            # executable graph is instantiated by the first replay
-            graph = torch.cuda.CUDAGraph(keep_graph=True)
-            with torch.cuda.graph(graph), mode():
+            def body():
                 base.add_(_SEED_STEP)
-                out = self.fn(*static)
-            # A captured hipMemsetAsync replays a WRONG fill pattern on ROCm 7.2 from the second replay on when other work
-            # runs in between (tools/probes/graph_memset_probe.py), and library code inside the step issues such memsets
-            # (PyTorch's reduction semaphores, hipBLASLt's split-K workspaces: tools/diag_memset_sites.py).  Before the
-            # graph is instantiated every memset node is therefore replaced by a fill-kernel node
-            # (cwlt_graph_replace_memset_nodes); `census` records the node kinds before that, `memsets_replaced` how many
-            # were rewritten.  Should any memset node remain (inside a child graph), the capture is never replayed and the
-            # step keeps running eagerly -- the capture itself executed nothing.
-            raw = graph.raw_cuda_graph()
-            self.census = _lib.graph_node_census(raw)
-            self.memsets_replaced = 0
-            if self.census.get("memset", 0):
-                n = ctypes.c_int(0)
-                _lib.check(_lib.load().cwlt_graph_replace_memset_nodes(ctypes.c_void_p(int(raw)), ctypes.byref(n)),
-                           "cwlt_graph_replace_memset_nodes")
-                self.memsets_replaced = n.value
-                left = _lib.graph_node_census(raw).get("memset", 0)
-                if left:
-                    import warnings
-                    warnings.warn("GraphedCall: the captured %s still holds %d memset node(s) after the rewrite (%s); a "
-                                  "replayed hipMemsetAsync is not reliable on this runtime -- running this signature "
-                                  "eagerly instead" % (getattr(self.fn, "__name__", "step"), left, self.census))
-                    graph.reset()
-                    graph = None
+                return self.fn(*static)
+            graph, out, self.census, self.memsets_replaced = capture_hip_graph(
+                body, mode, getattr(self.fn, "__name__", "step"))
             if self._storage() != before:
                 raise RuntimeError("GraphedCall(grad=True): parameter / gradient storage changed DURING capture")
         finally:

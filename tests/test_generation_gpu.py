@@ -73,6 +73,10 @@ def test_decode_session_matches_reference_stream(cuda, graph, fused):
     for t in range(len(FIX["logits"])):
         got = sess.step(FIX["tokens"][t])
         assert np.abs(got - FIX["logits"][t]).max() < 1e-4, t
+    if graph:       # captured through ops.capture_hip_graph: counted, and free of memset nodes when it is replayed
+        assert sess.use_graph and sess.census.get("kernel", 0) > 0, sess.census
+        if fused:
+            assert sess.census.get("memset", 0) == 0, sess.census      # cwlt_decode_step issues kernels only
     # free running under the recorded np seed: the same token stream
     sess.reset()
     np.random.seed(int(FIX["np_seed"]))
