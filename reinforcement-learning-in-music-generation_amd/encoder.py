@@ -35,6 +35,9 @@ class TriangularCausalMask:
         self.lower_triangular = True
 
 
+DX1_IN_PLACE = os.environ.get("CWLT_DX1_IN_PLACE", "1") != "0"
+
+
 class _EncoderLayerFn(torch.autograd.Function):
     """One post-LN encoder layer (fast_transformers TransformerEncoderLayer + AttentionLayer +
     CausalLinearAttention), x: (N, L, D) -> (N, L, D)."""
@@ -136,7 +139,14 @@ class _EncoderLayerFn(torch.autograd.Function):
             dgact = dgrad(dy, w2_a)                                        # (R, F)
             dh, db1 = ops.gelu_bwd(dgact, h, b1f, p, seeds[1])
             del dgact
-        dx1 = dgrad(dh, w1_a)                                              # (R, D)
+        if DX1_IN_PLACE:
+            # linear1's input gradient lands ON the residual gradient (C = D = ds2, beta = 1): norm1's backward then
+            # reads one gradient stream instead of two, and the extra read sits in a GEMM that has HBM time to spare.
+            # dy may alias ds2 (p = 0); its last readers (dw2, dh) are already enqueued.
+            ds2.addmm_(dh, w1_a.t().contiguous().t() if nt else w1_a)       # (R, D)
+            dx1 = None
+        else:
+            dx1 = dgrad(dh, w1_a)                                          # (R, D)
         dw1 = wgrad(dh, x1)                                                # (F, D)
         del dh
         ds1, do, dg1, dbe1, dbo = ops.ln_bwd(ds2, dx1, s1, g1f, mean1, rstd1, p, seeds[0])
