@@ -217,6 +217,23 @@ int cwlt_cw_embed_fwd(const int64_t* tokens, const void* const* tables, const in
 int cwlt_cw_embed_bwd(const int64_t* tokens, const int* widths, const int* nrows, int n_attr,
                       const void* dout, float* part, float* dtables, int64_t rows, int64_t ldd,
                       int dtype, void* stream);
+/* The whole input front in one pass -- embedding x6 + cat + in_linear + PositionalEncoding
+ * (dqn_policy/model.py:206-223 and 90-92; ppo_policy/model.py:208-225) -- from PROJECTED tables:
+ *   out[r, :] = dropout(sum_f tproj[rowofs_f + tokens[r, f], :] + bias + pe[r % T, :]),  rowofs_f = sum_{g<f} nrows[g],
+ *   tproj = cat_f(sqrt(width_f) * table_f . W_in[:, cols_f]^T)   (sum nrows, D), built by the caller per step.
+ * The (rows, sum widths) concatenated embeddings and the in_linear GEMM over the token rows do not exist on this path.
+ * tproj has out's dtype (bf16 / f32), dense; bias (D), pe (max_len >= T, D) f32 (pe may be NULL); out (rows, D) dense;
+ * 16-byte aligned pointers; D % 64 == 0, D <= 2048; ids outside [0, nrows) are clamped; 0 <= p < 1.  The dropout
+ * stream is cwlt_posenc_dropout's for the same seed. */
+int cwlt_cw_embed_proj_fwd(const int64_t* tokens, const void* tproj, const int* nrows, int n_attr,
+                           const float* bias, const float* pe, void* out, int64_t rows, int T, int D,
+                           float p, uint64_t seed, const uint64_t* seed_base, int dtype, void* stream);
+/* dtproj[rowofs_f + id, :] = sum of dpre[r, :] over the token rows with tokens[r, f] == id ((sum nrows, D) f32), dpre =
+ * the gradient in front of the dropout (cwlt_posenc_dropout(dout, pe = NULL) with the forward's seed), row stride ldd.
+ * The bias gradient is the column sum of any ONE attribute's rows of dtproj.
+ * part: cwlt_embed_splits(rows) * (sum nrows) * D f32.  Deterministic (no atomics). */
+int cwlt_cw_embed_proj_bwd(const int64_t* tokens, const int* nrows, int n_attr, int D, const void* dpre,
+                           float* part, float* dtproj, int64_t rows, int64_t ldd, int dtype, void* stream);
 
 /* ---- per-attribute softmax heads ----------------------------------------------------------------
  * logits (rows, ld), attribute f in columns [sum_{g<f} n_class[g], + n_class[f]) (n_class: HOST

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 14
+ABI_VERSION = 15
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -68,6 +68,9 @@ _SIGNATURES = {
     "cwlt_embed_splits": [_c_i64],
     "cwlt_cw_embed_fwd": [_ptr, _ptr, _ptr, _ptr, _c_int, _ptr, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_cw_embed_bwd": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_cw_embed_proj_fwd": [_ptr, _ptr, _ptr, _c_int, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr,
+                               _c_int, _ptr],
+    "cwlt_cw_embed_proj_bwd": [_ptr, _ptr, _c_int, _c_int, _ptr, _ptr, _ptr, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_band_attn_fwd": [_ptr] * 6 + [_c_int] * 5 + [_c_i64] * 4 + [_c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_band_attn_bwd": [_ptr] * 10 + [_c_int] * 5 + [_c_i64] * 8 + [_c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_wgrad_splits": [_c_i64, _c_int, _c_int],

@@ -197,6 +197,60 @@ __global__ __launch_bounds__(64, 2) void cw_embed_bwd_mfma_kernel(const int64_t*
     }
 }
 
+// ---- the whole input front in one pass -----------------------------------------------------------------------------
+// in_linear(cat_f(table_f[tok_f] * sqrt(w_f))) = sum_f P_f[tok_f] + b  with the PROJECTED tables
+// P_f = sqrt(w_f) * table_f . W_in[:, cols_f]^T  (n_f x D; 339 rows in all at the repo's vocabularies, built by the
+// caller with six small GEMMs per step), so embedding, concatenation, in_linear, positional encoding and dropout
+// (dqn_policy/model.py:206-223 + 90-92) are ONE pass that reads 48 bytes of ids per token and writes the (rows, D)
+// activations: the (rows, 1216) concatenated embeddings and the 1216 -> 512 GEMM over all token rows are gone.
+// A thread owns V = 16-byte-of-output adjacent columns of a row (the posenc kernel's shape, so that the dropout stream
+// is the one cwlt_posenc_dropout draws for the same seed: key = element offset r * D + c).  The tables are read from L2.
+template <typename T, typename TT>
+__global__ __launch_bounds__(256) void cw_embed_proj_fwd_kernel(const int64_t* __restrict__ tokens, const TT* __restrict__ tp,
+                                                                EmbedArgs a, const float* __restrict__ bias,
+                                                                const float* __restrict__ pe, T* __restrict__ out,
+                                                                long rows, int Tlen, int D, uint32_t thresh,
+                                                                float keep_scale, uint64_t seed,
+                                                                const uint64_t* __restrict__ seed_base) {
+    if (seed_base) seed += *seed_base;
+    constexpr int V = VecIO<T>::N;
+    const int nd = D / V;
+    const long nv = rows * (long)nd;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+        const long r = i / nd;
+        const int c = (int)(i - r * nd) * V;
+        float t[V];
+        loadf<V>(bias + c, t);
+        if (pe) {
+            float q[V];
+            loadf<V>(pe + (r % Tlen) * (long)D + c, q);
+#pragma unroll
+            for (int j = 0; j < V; ++j) t[j] += q[j];
+        }
+        // the rows of all attributes are requested before the first is added
+        float v[CWLT_MAX_ATTR][V];
+#pragma unroll
+        for (int f = 0; f < CWLT_MAX_ATTR; ++f)
+            if (f < a.n_attr) {
+                const int id = clamp_id(tokens[r * a.n_attr + f], a.nrows[f]);
+                VecIO<TT>::load(tp + a.tabofs[f] + (long)id * D + c, v[f]);
+            }
+#pragma unroll
+        for (int f = 0; f < CWLT_MAX_ATTR; ++f)
+            if (f < a.n_attr) {
+#pragma unroll
+                for (int j = 0; j < V; ++j) t[j] += v[f][j];
+            }
+        const long off = r * D + c;
+        if (thresh) {
+            const uint32_t km = dropout_mask<V>(seed, off, thresh);
+#pragma unroll
+            for (int j = 0; j < V; ++j) t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
+        }
+        VecIO<T>::store(out + off, t);
+    }
+}
+
 static int fill_args(EmbedArgs& a, const void* const* tables, const int* widths, const int* nrows, int n_attr) {
     if (!tables || !widths || !nrows || n_attr <= 0 || n_attr > CWLT_MAX_ATTR) return CWLT_ERR_ARG;
     int off = 0, tot = 0;
@@ -215,6 +269,26 @@ static int fill_args(EmbedArgs& a, const void* const* tables, const int* widths,
     a.dcat = off;
     a.total = tot;
     return off > 2048 ? CWLT_ERR_ARG : CWLT_OK;
+}
+
+// projected tables: every attribute D columns wide, all reading / writing the SAME D columns
+static int fill_proj_args(EmbedArgs& a, const int* nrows, int n_attr, int D) {
+    if (!nrows || n_attr <= 0 || n_attr > CWLT_MAX_ATTR || D <= 0 || (D & 63) || D > 2048) return CWLT_ERR_ARG;
+    int rows = 0;
+    for (int f = 0; f < n_attr; ++f) {
+        if (nrows[f] <= 0) return CWLT_ERR_ARG;
+        a.tab[f] = nullptr;
+        a.width[f] = D;
+        a.nrows[f] = nrows[f];
+        a.off[f] = 0;
+        a.tabofs[f] = rows * D;
+        a.scale[f] = 1.0f;
+        rows += nrows[f];
+    }
+    a.n_attr = n_attr;
+    a.dcat = n_attr * D;
+    a.total = rows * D;
+    return CWLT_OK;
 }
 
 }  // namespace cwlt
@@ -297,6 +371,84 @@ int cwlt_cw_embed_bwd(const int64_t* tokens, const int* widths, const int* nrows
     e = (int)hipGetLastError();
     if (e) return e;
     return launch_colsum_finalize(part, dtables, ns, (long)a.total, a.total, 1.0f, 0, st);
+}
+
+/* out[r, :] = dropout(sum_f tproj[rowofs_f + tokens[r, f], :] + bias + pe[r % T, :]),  rowofs_f = sum_{g<f} nrows[g]:
+ * embedding x6 + cat + in_linear + PositionalEncoding (dqn_policy/model.py:206-223, 90-92) in one pass over the token
+ * rows, from the PROJECTED tables tproj = cat_f(sqrt(w_f) table_f . W_in[:, cols_f]^T) (sum nrows, D) that the caller
+ * builds per step.  tproj has the dtype of out (bf16 / f32), dense; bias (D) and pe (max_len >= T, D) f32, pe may be NULL;
+ * out (rows, D) dense, 16-byte aligned; D % 64 == 0.  The dropout stream is cwlt_posenc_dropout's for the same seed. */
+int cwlt_cw_embed_proj_fwd(const int64_t* tokens, const void* tproj, const int* nrows, int n_attr, const float* bias,
+                           const float* pe, void* out, int64_t rows, int T, int D, float p, uint64_t seed,
+                           const uint64_t* seed_base, int dtype, void* stream) {
+    using namespace cwlt;
+    EmbedArgs a;
+    int e = fill_proj_args(a, nrows, n_attr, D);
+    if (e) return e;
+    if (rows < 0 || T <= 0 || p < 0.f || p >= 1.f) return CWLT_ERR_ARG;
+    if (rows == 0) return CWLT_OK;
+    if (!tokens || !tproj || !bias || !out || (((uintptr_t)out | (uintptr_t)tproj | (uintptr_t)bias | (uintptr_t)pe) & 15))
+        return CWLT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t th = drop_thresh(p);
+    const float ks = drop_scale(p);
+    long nb = (rows * (D / (dtype == CWLT_BF16 ? 8 : 4)) + 255) / 256;
+    if (nb > 256 * 32) nb = 256 * 32;
+    if (dtype == CWLT_F32)
+        hipLaunchKernelGGL((cw_embed_proj_fwd_kernel<float, float>), dim3((unsigned)nb), dim3(256), 0, st, tokens,
+                           (const float*)tproj, a, bias, pe, (float*)out, (long)rows, T, D, th, ks, seed, seed_base);
+    else if (dtype == CWLT_BF16)
+        hipLaunchKernelGGL((cw_embed_proj_fwd_kernel<bf16_t, bf16_t>), dim3((unsigned)nb), dim3(256), 0, st, tokens,
+                           (const bf16_t*)tproj, a, bias, pe, (bf16_t*)out, (long)rows, T, D, th, ks, seed, seed_base);
+    else
+        return CWLT_ERR_DTYPE;
+    return (int)hipGetLastError();
+}
+
+/* dtproj[rowofs_f + id, :] = sum over the token rows r with tokens[r, f] == id of dpre[r, :]  (f32, (sum nrows, D)):
+ * the gradient of cwlt_cw_embed_proj_fwd's projected tables from dpre = the gradient in front of the dropout
+ * (cwlt_posenc_dropout with pe == NULL applied to dout).  The bias gradient is any one attribute's rows of dtproj summed.
+ * part: cwlt_embed_splits(rows) * (sum nrows) * D f32.  dpre (rows, D) with row stride ldd.  Deterministic. */
+int cwlt_cw_embed_proj_bwd(const int64_t* tokens, const int* nrows, int n_attr, int D, const void* dpre, float* part,
+                           float* dtproj, int64_t rows, int64_t ldd, int dtype, void* stream) {
+    using namespace cwlt;
+    EmbedArgs a;
+    int e = fill_proj_args(a, nrows, n_attr, D);
+    if (e) return e;
+    if (!dtproj || rows < 0 || ldd < D) return CWLT_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (rows == 0) return (int)hipMemsetAsync(dtproj, 0, sizeof(float) * a.total, st);
+    if (!tokens || !dpre || !part) return CWLT_ERR_ARG;
+    int maxr = 0;
+    for (int f = 0; f < n_attr; ++f) maxr = nrows[f] > maxr ? nrows[f] : maxr;
+    const size_t lds = (size_t)maxr * 64 * sizeof(float);
+    if (lds > 160 * 1024) return CWLT_ERR_ARG;
+    const int ns = cwlt_embed_splits(rows);
+    // the six attributes of a column slab are neighbours in the grid (x = attribute-major would put them 8 apart: the
+    // same XCD either way under round-robin placement), so the slab of dpre they all read is fetched from HBM once
+    const dim3 grid(a.dcat / 64, ns), block(64);
+    if (dtype == CWLT_F32) {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void*)cw_embed_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        hipLaunchKernelGGL((cw_embed_bwd_kernel<float>), grid, block, lds, st, tokens, a, (const float*)dpre, part,
+                           (long)rows, (long)ldd);
+    } else if (dtype == CWLT_BF16 && maxr <= 32 * EB_MT && (rows + ns - 1) / ns <= EB_MAXROWS && !(ldd & 7) &&
+               !((uintptr_t)dpre & 15)) {
+        hipLaunchKernelGGL(cw_embed_bwd_mfma_kernel, grid, block, 0, st, tokens, a, (const bf16_t*)dpre, part, (long)rows,
+                           (long)ldd);
+    } else if (dtype == CWLT_BF16) {
+        if (lds > 64 * 1024)
+            hipFuncSetAttribute((const void*)cw_embed_bwd_kernel<bf16_t>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        hipLaunchKernelGGL((cw_embed_bwd_kernel<bf16_t>), grid, block, lds, st, tokens, a, (const bf16_t*)dpre, part,
+                           (long)rows, (long)ldd);
+    } else {
+        return CWLT_ERR_DTYPE;
+    }
+    e = (int)hipGetLastError();
+    if (e) return e;
+    return launch_colsum_finalize(part, dtproj, ns, (long)a.total, a.total, 1.0f, 0, st);
 }
 
 }  // extern "C"

@@ -139,7 +139,22 @@ class CWTrunk(nn.Module):
         loss = ops.heads_ce(logits, target.reshape(-1, 1), loss_mask, (predict.shape[1],))
         return loss[0]
 
+    def embed_pos(self, x):
+        """(N, T, 6) int64 -> (N, T, d_model): embedding + in_linear + positional encoding + dropout in one pass over
+        the token rows (ops.EmbedProjFn: projected tables; the (N, T, 1216) embeddings are never materialised)."""
+        if not x.is_cuda:
+            raise RuntimeError("rlmg_amd models run on the GPU only (no CPU fallback): move inputs to cuda")
+        pe = self.pos_emb
+        p = pe.dropout.p if pe.training else 0.0
+        return ops.embed_proj(x, self._tables(), self.in_linear.weight, self.in_linear.bias, pe.pe, p,
+                              ops.next_seed() if p > 0 else 0, self.compute_dtype)
+
     def forward_hidden(self, x, memory=None, is_training=True):
+        if (is_training and ops.EMBED_PROJ and x.dim() == 3 and not self._recurrent
+                and x.shape[0] * x.shape[1] >= ops.EMBED_PROJ_MIN_ROWS):
+            pos_emb = self.embed_pos(x)
+            attn_mask = TriangularCausalMask(pos_emb.size(1), device=x.device)
+            return self.transformer_encoder(pos_emb, attn_mask)
         emb_linear = self.embed(x)
         if is_training:
             if self._recurrent:

@@ -881,6 +881,74 @@ def cw_embed(tokens, tables, out_dtype=torch.float32):
     return CWEmbedFn.apply(tokens, out_dtype, *tables)
 
 
+EMBED_PROJ = os.environ.get("CWLT_EMBED_PROJ", "1") != "0"
+# below this many token rows the front's three kernels cost nothing on the GPU and the ~14 small launches that build the
+# projected tables are a net loss for the launch-bound RL steps
+EMBED_PROJ_MIN_ROWS = int(os.environ.get("CWLT_EMBED_PROJ_MIN_ROWS", "8192"))
+
+
+class EmbedProjFn(torch.autograd.Function):
+    """The model's input front in one pass (dqn_policy/model.py:206-223 + 90-92):
+    dropout(in_linear(cat_f(lut_f(x_f) * sqrt(d_f))) + pe[:, :T]) = dropout(sum_f P_f[x_f] + b + pe) with the projected
+    tables P = cat_f(sqrt(d_f) lut_f . W_in[:, cols_f]^T) ((sum n_f, D) f32, built by the caller with differentiable
+    torch ops, so autograd carries dP on to the tables and to in_linear.weight).  tokens (N, T, A) int64 ->
+    (N, T, D) of `out_dtype`.  Backward: dP = the scatter-add of the gradient in front of the dropout over the ids (the
+    one-hot MFMA GEMM of cwlt_cw_embed_bwd), db = the column sum of one attribute's rows of dP."""
+
+    @staticmethod
+    def forward(ctx, tokens, tproj, bias, pe, nrows, p, seed, out_dtype):
+        if tokens.dtype != torch.int64:
+            raise TypeError("tokens must be int64 (the reference indexes nn.Embedding with .long())")
+        N, T, A = tokens.shape
+        if A != len(nrows):
+            raise ValueError("tokens carry %d attributes, model has %d tables" % (A, len(nrows)))
+        D = tproj.shape[1]
+        if tproj.shape[0] != sum(nrows) or bias.shape != (D,):
+            raise ValueError("projected tables / bias do not match the vocabularies")
+        if pe is not None:
+            pe = pe.reshape(-1, D)
+            if T > pe.shape[0]:
+                raise RuntimeError("sequence length %d exceeds the positional table (%d)" % (T, pe.shape[0]))
+        tok = tokens.reshape(-1, A).contiguous()
+        rows = tok.shape[0]
+        tp = tproj.detach().to(out_dtype).contiguous()
+        out = torch.empty((rows, D), dtype=out_dtype, device=tok.device)
+        _call("cwlt_cw_embed_proj_fwd", _lib.dev(tok, "tokens"), _lib.dev(tp), _lib.int_array(nrows), A,
+              _lib.dev(_f32(bias)), _lib.opt(None if pe is None else _f32(pe)), _lib.dev(out), rows, int(T), D, float(p),
+              int(seed), _seed_base(), _lib.dtype_code(out_dtype), _lib.stream_ptr())
+        ctx.save_for_backward(tok)
+        ctx.cfg = (list(nrows), T, D, p, seed)
+        return out.view(N, T, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = _lib.load()
+        (tok,) = ctx.saved_tensors
+        nrows, T, D, p, seed = ctx.cfg
+        A = len(nrows)
+        d2 = dout.reshape(-1, D)
+        dpre = posenc_dropout(d2, None, T, p, seed) if p > 0 else d2.contiguous()
+        rows = dpre.shape[0]
+        total = sum(nrows) * D
+        part = torch.empty(lib.cwlt_embed_splits(rows) * total, dtype=torch.float32, device=dpre.device)
+        dtp = torch.empty((sum(nrows), D), dtype=torch.float32, device=dpre.device)
+        _call("cwlt_cw_embed_proj_bwd", _lib.dev(tok), _lib.int_array(nrows), A, D, _lib.dev(dpre, "dpre"), _lib.dev(part),
+              _lib.dev(dtp), rows, D, _lib.dtype_code(dpre.dtype), _lib.stream_ptr())
+        dbias = dtp[:nrows[0]].sum(0)             # every token row has exactly one id of attribute 0
+        return None, dtp, dbias, None, None, None, None, None
+
+
+def embed_proj(tokens, tables, w_in, b_in, pe, p, seed, out_dtype):
+    """tokens (N, T, A); tables: A embedding weights (n_f, d_f) f32; w_in (D, sum d_f), b_in (D); pe (.., max_len, D)."""
+    cols, parts = 0, []
+    for t in tables:
+        d = t.shape[1]
+        parts.append(torch.nn.functional.linear(t * math.sqrt(d), w_in[:, cols:cols + d]))
+        cols += d
+    tproj = torch.cat(parts, 0)
+    return EmbedProjFn.apply(tokens, tproj, b_in, pe, tuple(t.shape[0] for t in tables), p, seed, out_dtype)
+
+
 # --------------------------------------------------------------------------------------------------
 # per-attribute heads
 # --------------------------------------------------------------------------------------------------

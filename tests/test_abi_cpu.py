@@ -70,6 +70,17 @@ def test_argument_validation_without_gpu(built):
     assert lib.cwlt_causal_linear_fwd(buf, buf, buf, buf, buf, 1, 8, L9, 64, 512, 512, 512, 512, 1e-6, 10, buf, null, 1, null) == 1001
     # (3 segments of 3 chunks is what cwlt_scan_segments would hand out for such a length; not launched here: no GPU)
     assert lib.cwlt_sample_categorical(buf, (ctypes.c_int * 2)(5, 300), None, None, 2, 1, 305, 0, null, buf, null, 0, null) == 1001
+    # one-pass input front: D must be a multiple of 64, T positive, p < 1, vocabularies positive -- all before any launch
+    nr = (ctypes.c_int * 6)(56, 135, 18, 87, 18, 25)
+    buf16 = ctypes.c_void_p(4096)
+    assert lib.cwlt_cw_embed_proj_fwd(buf16, buf16, nr, 6, buf16, null, buf16, 8, 4, 500, 0.0, 0, null, 1, null) == 1001
+    assert lib.cwlt_cw_embed_proj_fwd(buf16, buf16, nr, 6, buf16, null, buf16, 8, 0, 512, 0.0, 0, null, 1, null) == 1001
+    assert lib.cwlt_cw_embed_proj_fwd(buf16, buf16, nr, 6, buf16, null, buf16, 8, 4, 512, 1.0, 0, null, 1, null) == 1001
+    assert lib.cwlt_cw_embed_proj_fwd(buf16, buf16, nr, 9, buf16, null, buf16, 8, 4, 512, 0.0, 0, null, 1, null) == 1001
+    assert lib.cwlt_cw_embed_proj_fwd(buf16, null, nr, 6, buf16, null, buf16, 8, 4, 512, 0.0, 0, null, 1, null) == 1001
+    assert lib.cwlt_cw_embed_proj_fwd(buf16, buf16, nr, 6, buf16, null, buf16, 0, 4, 512, 0.0, 0, null, 1, null) == 0   # no rows
+    assert lib.cwlt_cw_embed_proj_bwd(buf16, nr, 6, 512, buf16, buf16, buf16, 8, 256, 1, null) == 1001      # ldd < D
+    assert lib.cwlt_cw_embed_proj_bwd(buf16, nr, 6, 512, buf16, buf16, null, 8, 512, 1, null) == 1001
     # generation step: an incomplete model description is refused before any launch
     m = built.DecodeModel()
     assert lib.cwlt_decode_workspace_floats(ctypes.byref(m)) == -1
