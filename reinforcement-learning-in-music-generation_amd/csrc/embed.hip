@@ -205,6 +205,7 @@ __global__ __launch_bounds__(64, 2) void cw_embed_bwd_mfma_kernel(const int64_t*
 // activations: the (rows, 1216) concatenated embeddings and the 1216 -> 512 GEMM over all token rows are gone.
 // A thread owns V = 16-byte-of-output adjacent columns of a row (the posenc kernel's shape, so that the dropout stream
 // is the one cwlt_posenc_dropout draws for the same seed: key = element offset r * D + c).  The tables are read from L2.
+constexpr int EP_TILE = 32;   // token rows per block iteration
 template <typename T, typename TT>
 __global__ __launch_bounds__(256) void cw_embed_proj_fwd_kernel(const int64_t* __restrict__ tokens, const TT* __restrict__ tp,
                                                                 EmbedArgs a, const float* __restrict__ bias,
@@ -212,42 +213,182 @@ __global__ __launch_bounds__(256) void cw_embed_proj_fwd_kernel(const int64_t* _
                                                                 long rows, int Tlen, int D, uint32_t thresh,
                                                                 float keep_scale, uint64_t seed,
                                                                 const uint64_t* __restrict__ seed_base) {
+    // element offsets of the EP_TILE x n_attr table rows of a tile: the ids are read once, coalesced, and the table loads
+    // of a row do not wait behind an id load of their own (two dependent memory round trips per row otherwise)
+    __shared__ int ofs[EP_TILE * CWLT_MAX_ATTR];
     if (seed_base) seed += *seed_base;
     constexpr int V = VecIO<T>::N;
-    const int nd = D / V;
-    const long nv = rows * (long)nd;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
-        const long r = i / nd;
-        const int c = (int)(i - r * nd) * V;
-        float t[V];
-        loadf<V>(bias + c, t);
-        if (pe) {
-            float q[V];
-            loadf<V>(pe + (r % Tlen) * (long)D + c, q);
-#pragma unroll
-            for (int j = 0; j < V; ++j) t[j] += q[j];
+    const int nd = D / V, A = a.n_attr;
+    const long ntile = (rows + EP_TILE - 1) / EP_TILE;
+    for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+        const long r0 = tile * EP_TILE;
+        const int nr = (int)min((long)EP_TILE, rows - r0);
+        __syncthreads();                                   // the previous tile's offsets are no longer read
+        if ((int)threadIdx.x < nr * A) {
+            const int f = threadIdx.x % A;
+            ofs[threadIdx.x] = a.tabofs[f] + clamp_id(tokens[r0 * A + threadIdx.x], a.nrows[f]) * D;
         }
-        // the rows of all attributes are requested before the first is added
-        float v[CWLT_MAX_ATTR][V];
+        __syncthreads();
+#pragma unroll 2
+        for (int i = threadIdx.x; i < nr * nd; i += 256) {
+            const int row = i / nd, c = (i - row * nd) * V;
+            const long r = r0 + row;
+            float v[CWLT_MAX_ATTR][V];
 #pragma unroll
-        for (int f = 0; f < CWLT_MAX_ATTR; ++f)
-            if (f < a.n_attr) {
-                const int id = clamp_id(tokens[r * a.n_attr + f], a.nrows[f]);
-                VecIO<TT>::load(tp + a.tabofs[f] + (long)id * D + c, v[f]);
+            for (int f = 0; f < CWLT_MAX_ATTR; ++f)
+                if (f < A) VecIO<TT>::load(tp + ofs[row * A + f] + c, v[f]);
+            float t[V];
+            loadf<V>(bias + c, t);
+            if (pe) {
+                float q[V];
+                loadf<V>(pe + (r % Tlen) * (long)D + c, q);
+#pragma unroll
+                for (int j = 0; j < V; ++j) t[j] += q[j];
             }
 #pragma unroll
-        for (int f = 0; f < CWLT_MAX_ATTR; ++f)
-            if (f < a.n_attr) {
+            for (int f = 0; f < CWLT_MAX_ATTR; ++f)
+                if (f < A) {
 #pragma unroll
-                for (int j = 0; j < V; ++j) t[j] += v[f][j];
+                    for (int j = 0; j < V; ++j) t[j] += v[f][j];
+                }
+            const long off = r * D + c;
+            if (thresh) {
+                const uint32_t km = dropout_mask<V>(seed, off, thresh);
+#pragma unroll
+                for (int j = 0; j < V; ++j) t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
             }
-        const long off = r * D + c;
-        if (thresh) {
-            const uint32_t km = dropout_mask<V>(seed, off, thresh);
-#pragma unroll
-            for (int j = 0; j < V; ++j) t[j] = ((km >> j) & 1u) ? t[j] * keep_scale : 0.f;
+            VecIO<T>::store(out + off, t);
         }
-        VecIO<T>::store(out + off, t);
+    }
+}
+
+// dP of the projected tables (cwlt_cw_embed_proj_bwd, bf16): every attribute's one-hot GEMM contracts the SAME 64-column
+// slab of dpre, so one workgroup stages the slab once and its four waves share it.  The work is cut into UNITS = (attribute,
+// 32-id tile) pairs -- 13 at the repo's vocabularies (2 + 5 + 1 + 3 + 1 + 1) -- dealt to the waves in order, at most
+// PB_MAXU per wave; per 64-row step a wave reads the slab's 8 transposed fragments once and issues 8 MFMAs per unit.
+// (cw_embed_bwd_mfma_kernel run once per attribute reads the slab six times and builds every tile in every workgroup:
+// 0.71 ms at the bench shape; this kernel: see DESIGN 4.3a.)
+constexpr int PB_NW = 4;            // waves per workgroup
+constexpr int PB_MAXU = 4;          // units per wave
+constexpr int PB_CHUNK = 1024;      // token rows whose ids (all attributes, 16 bits each) sit in LDS at a time
+constexpr int PB_STEP = 64;         // token rows per step
+constexpr int PB_MAXSPLITS = 64;    // row splits (workgroups per column slab): 8 x 64 = 512 workgroups at D = 512
+
+// eight one-hot bf16 values (1.0 where the 16-bit id equals m) from four id pairs: per pair x = id - m, min(x, 1) - 1 =
+// 0xffff where equal, & 0x3f80 -- four packed 16-bit instructions instead of two compares, two selects and a pack
+__device__ __forceinline__ uint32_t onehot_pair(uint32_t idp, uint32_t mp) {
+    uint32_t r;
+    const uint32_t one = 0x00010001u, bf1 = 0x3f803f80u;
+    asm("v_pk_sub_u16 %0, %1, %2\n\t"               // 0 where the id is this lane's row
+        "v_pk_min_u16 %0, %0, %3\n\t"               // 0 equal, 1 not
+        "v_pk_sub_u16 %0, %0, %3\n\t"               // 0xffff equal, 0 not
+        "v_and_b32 %0, %4, %0"                         // bf16 1.0 / 0.0
+        : "=&v"(r)
+        : "v"(idp), "v"(mp), "s"(one), "s"(bf1));
+    return r;
+}
+
+__global__ __launch_bounds__(256) void cw_embed_proj_bwd_mfma_kernel(const int64_t* __restrict__ tokens, EmbedArgs a,
+                                                                     const bf16_t* __restrict__ dpre,
+                                                                     float* __restrict__ part, long rows, long ldd, int D) {
+    using namespace b16;
+    __shared__ __attribute__((aligned(16))) bf16_t ts[2][PB_STEP * LD];          // dpre tile [64 token rows][64 cols] x 2
+    __shared__ __attribute__((aligned(16))) unsigned short ids[CWLT_MAX_ATTR][PB_CHUNK];
+    const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hf = lane >> 5;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cb = blockIdx.x, A = a.n_attr;
+    // row split of this workgroup, in whole steps
+    const long nstep_all = (rows + PB_STEP - 1) / PB_STEP;
+    const long sper = (nstep_all + gridDim.y - 1) / gridDim.y;
+    const long r0 = (long)blockIdx.y * sper * PB_STEP, r1 = min(rows, r0 + sper * PB_STEP);
+    // this wave's units
+    int total_u = 0;
+    for (int f = 0; f < A; ++f) total_u += (a.nrows[f] + 31) >> 5;
+    const int upw = (total_u + PB_NW - 1) / PB_NW;        // <= PB_MAXU (launcher)
+    int uf[PB_MAXU];                                      // attribute of unit u (-1: no unit)
+    uint32_t um[PB_MAXU];                                 // this lane's id row of unit u, in both 16-bit halves
+    {
+        int u = 0;
+#pragma unroll
+        for (int k = 0; k < PB_MAXU; ++k) uf[k] = -1, um[k] = 0;
+        for (int f = 0; f < A; ++f)
+            for (int mt = 0; mt < ((a.nrows[f] + 31) >> 5); ++mt, ++u) {
+                const int k = u - w * upw;
+#pragma unroll
+                for (int kk = 0; kk < PB_MAXU; ++kk)
+                    if (kk == k && k < upw) uf[kk] = f, um[kk] = (uint32_t)(32 * mt + l31) * 0x10001u;
+            }
+    }
+    f32x16 acc[PB_MAXU][2];
+#pragma unroll
+    for (int k = 0; k < PB_MAXU; ++k) acc[k][0] = zero16(), acc[k][1] = zero16();
+    const bf16_t* dp = dpre + cb * 64;
+    const int trow = tid >> 2, tcol = (tid & 3) * 16;     // 64 rows x 4 pieces of 16 columns
+    uint4 p0, p1;
+    for (long c0 = r0; c0 < r1; c0 += PB_CHUNK) {
+        const int n = (int)min((long)PB_CHUNK, r1 - c0);
+        const int npad = (n + PB_STEP - 1) / PB_STEP * PB_STEP;
+        __syncthreads();                                  // the previous chunk's ids and tiles are no longer read
+        for (int i = tid; i < npad * A; i += 256) {
+            const int r = i / A, f = i - r * A;
+            ids[f][r] = r < n ? (unsigned short)clamp_id(tokens[(c0 + r) * A + f], a.nrows[f]) : (unsigned short)0xffffu;
+        }
+        // this chunk's rows of the 64-column slab as a buffer resource: rows >= n read back as zeros
+        const __amdgpu_buffer_rsrc_t dr = make_rsrc(dp + c0 * ldd, (uint32_t)(((long)(n - 1) * ldd + 64) * 2));
+#define PB_LOAD(k0)                                                                              \
+    {                                                                                            \
+        const uint32_t off = ((uint32_t)((k0) + trow) * (uint32_t)ldd + tcol) * 2;               \
+        p0 = buf_load16(dr, off);                                                                \
+        p1 = buf_load16(dr, off + 16);                                                           \
+    }
+#define PB_PUT(b)                                                                                \
+    {                                                                                            \
+        *reinterpret_cast<uint4*>(ts[b] + trow * LD + tcol) = p0;                                \
+        *reinterpret_cast<uint4*>(ts[b] + trow * LD + tcol + 8) = p1;                            \
+    }
+        PB_LOAD(0);
+        PB_PUT(0);
+        __syncthreads();                                  // tile 0 and the ids
+        for (int k0 = 0, b = 0; k0 < npad; k0 += PB_STEP, b ^= 1) {
+            const bool more = k0 + PB_STEP < npad;
+            if (more) { PB_LOAD(k0 + PB_STEP); }
+#pragma unroll
+            for (int ks = 0; ks < PB_STEP / 16; ++ks) {
+                const bf16x8 b0 = tfrag8(ts[b], 16 * ks, 0, lane), b1 = tfrag8(ts[b], 16 * ks, 32, lane);
+#pragma unroll
+                for (int k = 0; k < PB_MAXU; ++k) {
+                    if (uf[k] >= 0) {
+                        const uint4 ip = *reinterpret_cast<const uint4*>(ids[uf[k]] + k0 + 16 * ks + 8 * hf);
+                        const uint4 o = make_uint4(onehot_pair(ip.x, um[k]), onehot_pair(ip.y, um[k]),
+                                                   onehot_pair(ip.z, um[k]), onehot_pair(ip.w, um[k]));
+                        const bf16x8 oh = __builtin_bit_cast(bf16x8, o);
+                        acc[k][0] = mfma(oh, b0, acc[k][0]);
+                        acc[k][1] = mfma(oh, b1, acc[k][1]);
+                    }
+                }
+            }
+            if (more) { PB_PUT(b ^ 1); }
+            __syncthreads();                              // next tile written, this one no longer read
+        }
+#undef PB_LOAD
+#undef PB_PUT
+    }
+    float* pp = part + (long)blockIdx.y * a.total + cb * 64;
+#pragma unroll
+    for (int k = 0; k < PB_MAXU; ++k) {
+        if (uf[k] >= 0) {
+            const int nr = a.nrows[uf[k]];
+            float* pt = pp + a.tabofs[uf[k]];
+            const int m0 = (int)(um[k] & 0xffffu) - l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int id = m0 + acc_row(r, hf);
+                if (id < nr) {
+                    pt[(long)id * D + l31] = acc[k][0][r];
+                    pt[(long)id * D + 32 + l31] = acc[k][1][r];
+                }
+            }
+        }
     }
 }
 
@@ -392,7 +533,7 @@ int cwlt_cw_embed_proj_fwd(const int64_t* tokens, const void* tproj, const int* 
     hipStream_t st = (hipStream_t)stream;
     const uint32_t th = drop_thresh(p);
     const float ks = drop_scale(p);
-    long nb = (rows * (D / (dtype == CWLT_BF16 ? 8 : 4)) + 255) / 256;
+    long nb = (rows + EP_TILE - 1) / EP_TILE;
     if (nb > 256 * 32) nb = 256 * 32;
     if (dtype == CWLT_F32)
         hipLaunchKernelGGL((cw_embed_proj_fwd_kernel<float, float>), dim3((unsigned)nb), dim3(256), 0, st, tokens,
@@ -419,8 +560,11 @@ int cwlt_cw_embed_proj_bwd(const int64_t* tokens, const int* nrows, int n_attr, 
     hipStream_t st = (hipStream_t)stream;
     if (rows == 0) return (int)hipMemsetAsync(dtproj, 0, sizeof(float) * a.total, st);
     if (!tokens || !dpre || !part) return CWLT_ERR_ARG;
-    int maxr = 0;
-    for (int f = 0; f < n_attr; ++f) maxr = nrows[f] > maxr ? nrows[f] : maxr;
+    int maxr = 0, units = 0;
+    for (int f = 0; f < n_attr; ++f) {
+        maxr = nrows[f] > maxr ? nrows[f] : maxr;
+        units += (nrows[f] + 31) / 32;
+    }
     const size_t lds = (size_t)maxr * 64 * sizeof(float);
     if (lds > 160 * 1024) return CWLT_ERR_ARG;
     const int ns = cwlt_embed_splits(rows);
@@ -433,6 +577,15 @@ int cwlt_cw_embed_proj_bwd(const int64_t* tokens, const int* nrows, int n_attr, 
                                 (int)lds);
         hipLaunchKernelGGL((cw_embed_bwd_kernel<float>), grid, block, lds, st, tokens, a, (const float*)dpre, part,
                            (long)rows, (long)ldd);
+    } else if (dtype == CWLT_BF16 && units <= PB_NW * PB_MAXU && maxr < 65535 && !(ldd & 7) && !((uintptr_t)dpre & 15) &&
+               (int64_t)PB_CHUNK * ldd * 2 < (1ll << 31)) {
+        // fewer, longer row splits than the per-attribute kernels use (the caller's `part` is sized for more)
+        const int nsp = ns < PB_MAXSPLITS ? ns : PB_MAXSPLITS;
+        hipLaunchKernelGGL(cw_embed_proj_bwd_mfma_kernel, dim3(D / 64, nsp), dim3(64 * PB_NW), 0, st, tokens, a,
+                           (const bf16_t*)dpre, part, (long)rows, (long)ldd, D);
+        e = (int)hipGetLastError();
+        if (e) return e;
+        return launch_colsum_finalize(part, dtproj, nsp, (long)a.total, a.total, 1.0f, 0, st);
     } else if (dtype == CWLT_BF16 && maxr <= 32 * EB_MT && (rows + ns - 1) / ns <= EB_MAXROWS && !(ldd & 7) &&
                !((uintptr_t)dpre & 15)) {
         hipLaunchKernelGGL(cw_embed_bwd_mfma_kernel, grid, block, 0, st, tokens, a, (const bf16_t*)dpre, part, (long)rows,
