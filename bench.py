@@ -35,6 +35,7 @@ N_CLASS_DISK = [56, 135, 18, 3, 87, 18, 25]      # 7 on-disk fields incl. `type`
 HBM_PEAK_GBS = 8000.0                            # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 MFMA_BF16_PEAK = 2.5e15                          # dense bf16
 FLOP_PER_TOKEN = 236e6                           # fwd+bwd, repo dims
+PPO_GROUP = 16                                   # rollouts stacked per PPO update pass (bench_ppo.py --group)
 
 
 def synth_batch(B, T, seed, device):
@@ -233,7 +234,7 @@ def ppo_report(args, ppo, world):
     return {"metric": "PPO env-steps/sec", "value": round(ppo["env_steps_per_s"], 2), "unit": "env-steps/s",
             "rollout_only_env_steps_per_s": round(ppo["rollout_only_env_steps_per_s"], 2),
             "ms_per_iteration": round(ppo["ms_per_iteration"], 1), "n_gpus": world, "scaling": "weak",
-            "replica_spread": ppo["replica_spread"], "dominant_kernel": dom,
+            "replica_spread": ppo["replica_spread"], "hbm_peak_gb": ppo.get("hbm_peak_gb"), "dominant_kernel": dom,
             "config": {"workload": "ppo_train iteration (ppo_policy/ppo_train.py:460-506): %d rollouts/GPU x window %d, "
                                    "EPISODES 30, PPO_STEPS %d, actor/critic 512/12/8, reward Longformer 512/12/8 w=512; "
                                    "env-step = actor greedy fwd + critic value + reward model + buffer write; update: "
@@ -242,7 +243,7 @@ def ppo_report(args, ppo, world):
                                    "CE pass, critic pass, both backwards, two Adam steps; "
                                    "1 warm-up + 1 timed iteration" % (R, W, args.ppo_steps),
                        "rollouts_per_gpu": R, "window": W, "episodes": 30, "ppo_steps": args.ppo_steps,
-                       "update_group": 8, "hipgraph_rollout": ppo["hipgraph_rollout"],
+                       "update_group": ppo.get("update_group", PPO_GROUP), "hipgraph_rollout": ppo["hipgraph_rollout"],
                        "select_pass": ppo.get("select_pass", "last-state")}}
 
 
@@ -371,8 +372,23 @@ def main():
         import bench_ppo
         log("ppo block: %d rollouts x window %d, EPISODES %d, PPO_STEPS %d" % (args.ppo_rollouts, args.ppo_window, 30,
                                                                               args.ppo_steps))
-        ppo = bench_ppo.run(args.ppo_rollouts, args.ppo_window, 30, args.ppo_steps, iters=1, warmup=1, dtype=args.dtype,
-                            group=8, rank=rank, world=world, dev=dev, timer=True)
+        ppo_group = PPO_GROUP
+        try:
+            ppo = bench_ppo.run(args.ppo_rollouts, args.ppo_window, 30, args.ppo_steps, iters=1, warmup=1,
+                                dtype=args.dtype, group=ppo_group, rank=rank, world=world, dev=dev, timer=True)
+        except torch.OutOfMemoryError:
+            # 16 rollouts x 30 states x window 1024 per update pass peak at ~207 GB of the 288; should a box have less to
+            # give, the block is measured with 8 per pass (~110 GB) rather than lost.  One rank alone cannot take this
+            # path (the passes hold collectives), so under data parallelism the error is left to propagate.
+            if world > 1:
+                raise
+            log("ppo block: out of memory at %d rollouts per update pass, measuring with %d" % (ppo_group, ppo_group // 2))
+            gc.collect()
+            torch.cuda.empty_cache()
+            ppo_group //= 2
+            ppo = bench_ppo.run(args.ppo_rollouts, args.ppo_window, 30, args.ppo_steps, iters=1, warmup=1,
+                                dtype=args.dtype, group=ppo_group, rank=rank, world=world, dev=dev, timer=True)
+        ppo["update_group"] = ppo_group
 
     if rank == 0:
         s = 2 if args.dtype == "bf16" else 4

@@ -149,7 +149,8 @@ def run(rollouts=64, window=1024, episodes=30, ppo_steps=10, iters=1, warmup=1, 
     return {"env_steps_per_s": steps / dt, "rollout_only_env_steps_per_s": steps / t_roll,
             "ms_per_iteration": 1e3 * dt / iters, "replica_spread": replica_spread, "kernel_times": kernel_times,
             "hipgraph_rollout": bool(ops.GRAPHS_ENABLED), "tokens_per_update_pass": E * W * min(G, R),
-            "select_pass": "all-states" if P.SELECT_ALL_STATES else "last-state"}
+            "select_pass": "all-states" if P.SELECT_ALL_STATES else "last-state",
+            "hbm_peak_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)}
 
 
 def cpu_rollout_baseline(window=1024, seconds_budget=20.0):
@@ -210,7 +211,7 @@ def main():
     ap.add_argument("--iters", type=int, default=1)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--group", type=int, default=8, help="rollouts stacked per update pass (1 = one at a time)")
+    ap.add_argument("--group", type=int, default=16, help="rollouts stacked per update pass (1 = one at a time)")
     ap.add_argument("--tune-gemms", action="store_true", help="extend the GEMM table with this workload's shapes")
     ap.add_argument("--no-graphs", action="store_true", help="launch the rollout step eagerly (no hipGraph)")
     ap.add_argument("--cpu-baseline", action="store_true", help="also time one oracle rollout step on the host cores")
@@ -243,7 +244,7 @@ def main():
             "n_gpus": world, "steps": args.iters, "warmup": args.warmup, "ms_per_step": round(res["ms_per_iteration"], 1),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "rollout_only_env_steps_per_s": round(res["rollout_only_env_steps_per_s"], 2),
-            "replica_spread": res["replica_spread"],
+            "replica_spread": res["replica_spread"], "hbm_peak_gb": res["hbm_peak_gb"],
             "config": {"workload": "ppo_train iteration: %d rollouts/GPU x window %d, EPISODES %d, PPO_STEPS %d, "
                                    "actor/critic 512/12/8, reward Longformer 512/12/8 w=512" % (R, W, E, args.ppo_steps),
                        "hipgraph_rollout": res["hipgraph_rollout"], "update_group": max(1, args.group),
