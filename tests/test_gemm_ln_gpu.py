@@ -118,6 +118,10 @@ def test_encoder_with_the_one_kernel_residual_blocks_equals_the_two_kernel_path(
     # two bf16 schedules of the same step: each lies within a few per cent (norm-wise, per tensor) of the f32 gradient
     # (test_model_gpu.py: measured 1-5 %, bound 7.1 %); against EACH OTHER the bound is that figure relative to the
     # tensor's own norm
+    # tensor's own norm -- with test_model_gpu.py's floor of 1e-4 of the rms tensor norm for gradients that are rounding
+    # noise in both schedules (key_projection.bias: norm 7e-6 beside 1e-2 .. 1 for the rest; its two noise draws differ by
+    # 5-8 % of that)
+    rms = float(np.sqrt(np.mean([gb[k].norm().item() ** 2 for k in gb])))
     for k in gb:
         d = (ga[k] - gb[k]).norm().item()
-        assert d <= 7.1e-2 * gb[k].norm().item() + 1e-12, (k, d, gb[k].norm().item())
+        assert d <= 7.1e-2 * max(gb[k].norm().item(), 1e-4 * rms), (k, d, gb[k].norm().item(), rms)
