@@ -74,17 +74,21 @@ def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
         "cwlt_posenc_dropout": R * 2 * D * s,
         "cwlt_cw_embed_fwd": R * (48 + ncat * s),
         "cwlt_cw_embed_bwd": R * (48 + ncat * s),
+        # the one-pass input front (ops.EmbedProjFn): ids in, (R, D) activations out / gradient in (tables are L2-resident)
+        "cwlt_cw_embed_proj_fwd": R * (48 + D * s),
+        "cwlt_cw_embed_proj_bwd": R * (48 + D * s),
         "cwlt_heads_fwd": R * (W * s + 48 + 4),
         "cwlt_heads_ce_bwd": R * (2 * W * s + 48 + 4),
     }.get(entry)
 
 
-def wgrad_flops_per_step(B, T, D=512, F=2048, ncat=1216, W=384):
+def wgrad_flops_per_step(B, T, D=512, F=2048, ncat=1216, W=384, in_linear=False):
     """FLOPs of all weight-gradient GEMMs of one step, shape by shape: per layer dW2 (D x F), dW1 (F x D), dWo (D x D),
-    dWqkv (3D x D); once in_linear (D x 1216) and the fused head projection (384 x D).  (Cross-check of the per-call
-    figures the launches themselves declare through ops._call(work=...).)"""
+    dWqkv (3D x D); once the fused head projection (384 x D) and -- only with the three-kernel input front
+    (CWLT_EMBED_PROJ=0) -- in_linear (D x 1216): the one-pass front has no GEMM over the token rows.  (Cross-check of the
+    per-call figures the launches themselves declare through ops._call(work=...).)"""
     R = B * T
-    return 2.0 * R * (12 * (2 * D * F + D * D + 3 * D * D) + D * ncat + W * D)
+    return 2.0 * R * (12 * (2 * D * F + D * D + 3 * D * D) + (D * ncat if in_linear else 0) + W * D)
 
 
 def usable_cores():
@@ -201,7 +205,8 @@ def report(args, kt, B, T, s, world, ms_per_step, tokens_per_s, final_loss, repl
         if "cwlt_wgrad_bf16" in kt:                 # cross-check: declared per-call FLOPs vs the shape table
             c, m, work = kt["cwlt_wgrad_bf16"]
             kernels["cwlt_wgrad_bf16"]["flop_per_step_declared"] = work * c / n_sampled
-            kernels["cwlt_wgrad_bf16"]["flop_per_step_shapes"] = wgrad_flops_per_step(B, T)
+            kernels["cwlt_wgrad_bf16"]["flop_per_step_shapes"] = wgrad_flops_per_step(
+                B, T, in_linear="cwlt_cw_embed_proj_fwd" not in kernels)
     return {
         "metric": "CW-tokens/sec pretrain fwd+bwd @T=1024", "value": round(tokens_per_s, 1), "unit": "CW-tokens/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),

@@ -44,7 +44,7 @@ def test_report_picks_the_dominant_kernel_and_prices_the_scan_backward_as_one_un
     sys.path.insert(0, ROOT)
     import bench
     B, T, R = 512, 1024, 512 * 1024
-    flops = bench.wgrad_flops_per_step(B, T) / 50
+    flops = bench.wgrad_flops_per_step(B, T, in_linear=True) / 50      # a table without the one-pass front's kernels
     kt = {"cwlt_wgrad_bf16": (50, 0.72, flops),
           "cwlt_causal_linear_bwd_dkdv": (12, 1.0, None), "cwlt_causal_linear_bwd_dq": (12, 0.75, None),
           "cwlt_causal_linear_fwd": (12, 0.53, None), "cwlt_bias_gelu_dropout_bwd": (12, 1.29, None),
@@ -60,6 +60,16 @@ def test_report_picks_the_dominant_kernel_and_prices_the_scan_backward_as_one_un
     assert out["kernels"]["cwlt_causal_linear_bwd_dq"]["part_of"] == bench.SCAN_BWD
     assert "GB/s" not in out["kernels"]["cwlt_causal_linear_bwd_dq"]
     assert out["kernels"]["cwlt_wgrad_bf16"]["flop_per_step_declared"] == out["kernels"]["cwlt_wgrad_bf16"]["flop_per_step_shapes"]
+    # with the one-pass input front there is no in_linear weight-gradient GEMM over the token rows: 49 calls per step
+    kt2 = dict(kt)
+    kt2["cwlt_wgrad_bf16"] = (49, 0.72, bench.wgrad_flops_per_step(B, T) / 49)
+    kt2["cwlt_cw_embed_proj_fwd"] = (1, 0.42, None)
+    kt2["cwlt_cw_embed_proj_bwd"] = (1, 0.40, None)
+    out2 = bench.report(_args(), kt2, B, T, 2, 1, 190.0, B * T / 0.19, 3.9, None, True, 112.0)
+    w2 = out2["kernels"]["cwlt_wgrad_bf16"]
+    assert abs(w2["flop_per_step_declared"] - w2["flop_per_step_shapes"]) < 1e-6 * w2["flop_per_step_shapes"]
+    assert w2["flop_per_step_shapes"] < out["kernels"]["cwlt_wgrad_bf16"]["flop_per_step_shapes"]
+    assert abs(out2["kernels"]["cwlt_cw_embed_proj_fwd"]["GB/s"] - R * (48 + 512 * 2) / 0.42e-3 / 1e9) < 0.1
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline"):
         assert k in out, k

@@ -18,7 +18,8 @@ ENTRY = [("cla_fwd_bf16_kernel", "cwlt_causal_linear_fwd"), ("cla_bwd_sweep_bf16
          ("cla_bwd_dkdv_bf16_kernel", "cwlt_causal_linear_bwd_dkdv"), ("add_dropout_ln_fwd_kernel", "cwlt_add_dropout_layernorm_fwd"),
          ("add_dropout_ln_bwd_kernel", "cwlt_add_dropout_layernorm_bwd"), ("bias_gelu_dropout_fwd_kernel", "cwlt_bias_gelu_dropout_fwd"),
          ("bias_gelu_dropout_bwd_kernel", "cwlt_bias_gelu_dropout_bwd"), ("wgrad_kernel", "cwlt_wgrad_bf16"),
-         ("wgrad_reduce_kernel", "cwlt_wgrad_bf16"), ("cw_embed_bwd", "cwlt_cw_embed_bwd"), ("cw_embed_fwd", "cwlt_cw_embed_fwd"),
+         ("wgrad_reduce_kernel", "cwlt_wgrad_bf16"), ("cw_embed_proj_bwd", "cwlt_cw_embed_proj_bwd"),
+         ("cw_embed_proj_fwd", "cwlt_cw_embed_proj_fwd"), ("cw_embed_bwd", "cwlt_cw_embed_bwd"), ("cw_embed_fwd", "cwlt_cw_embed_fwd"),
          ("heads_fwd", "cwlt_heads_fwd"), ("heads_ce_bwd", "cwlt_heads_ce_bwd"), ("posenc_dropout_kernel", "cwlt_posenc_dropout"),
          ("gemm_ln_kernel", "cwlt_gemm_nt_bias_dropout_add_layernorm"), ("gemm_nt_mul_kernel<1", "cwlt_gemm_nt_bias_gelu_dropout"), ("gemm_nt_mul_kernel", "cwlt_gemm_nt_mul")]
 MAIN = {"cwlt_wgrad_bf16": "wgrad_kernel"}      # launches counted by the main kernel of multi-kernel entry points
