@@ -63,11 +63,19 @@ class Critic_Transformer(CWTrunk):
             setattr(self, name + "_value", nn.Linear(n, 1))
 
     def value_produce(self, x):
-        """(B, T, 6) -> (B, 1).  Linear(n_f -> 1) after Linear(512 -> n_f) and the mean over T commute
-        with each other, so the value is one (sum n_f)-wide dot per batch row of the T-mean logits."""
+        """(B, T, 6) -> (B, 1).  Everything behind the trunk is linear -- Linear(512 -> n_f), Linear(n_f -> 1), the mean
+        over T, the mean over the attributes (ppo_policy/model.py:345-394) -- so the mean over T is taken FIRST, on the
+        hidden states (f32 accumulation), and the heads see B rows instead of B * T: no (B * T, sum n_f) logits, no GEMM
+        over the token rows in either direction (the backward of a mean is a broadcast)."""
         h = self.forward_hidden(x)
-        B, T = h.shape[0], h.shape[1]
-        logits = self.fused_logits(h).float().view(B, T, -1).mean(dim=1)          # (B, W)
+        if os.environ.get("CWLT_CRITIC_MEAN_FIRST", "1") != "0":
+            hm = h.mean(dim=1, dtype=torch.float32)                                    # (B, D)
+            heads = self._heads()
+            logits = torch.nn.functional.linear(hm, torch.cat([m.weight for m in heads], 0),
+                                                torch.cat([m.bias for m in heads], 0))   # (B, sum n_f) = T-mean logits
+        else:
+            B, T = h.shape[0], h.shape[1]
+            logits = self.fused_logits(h).float().view(B, T, -1).mean(dim=1)          # (B, W)
         total = 0
         o = 0
         for name, n in zip(ATTRS, self.n_token):
