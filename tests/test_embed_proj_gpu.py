@@ -137,7 +137,7 @@ def test_model_loss_and_gradients_with_and_without_the_one_pass_front(cuda, monk
             torch.manual_seed(5)
             losses = net.train_step(x, y, mask)
             sum(losses).backward()
-            res.append(([float(v) for v in losses],
+            res.append(([float(v.detach()) for v in losses],
                         {k: p.grad.clone() for k, p in net.named_parameters() if p.grad is not None}))
         (l_on, g_on), (l_off, g_off) = res
         assert max(abs(a - b) for a, b in zip(l_on, l_off)) < 1e-4
@@ -146,3 +146,18 @@ def test_model_loss_and_gradients_with_and_without_the_one_pass_front(cuda, monk
             assert _rel(g_on[k], g_off[k]) < 2e-4, k
     finally:
         config.AgentConfig.update(old)
+
+
+@pytest.mark.parametrize("nrows,shape", [(NROWS, (3, 50)), (NROWS, (1, 1)), ((200, 300, 40, 150, 33, 64), (2, 100)),
+                                         ((56, 135, 18, 87, 18, 25), (5, 1000))])
+def test_bf16_backward_kernels_ragged_rows_and_large_vocabularies(cuda, nrows, shape):
+    """bf16 gradients of the projected tables on row counts that are not multiples of the 64-row step, on a single row,
+    across several 1 024-row id chunks of one split, and with vocabularies of more (attribute, 32-id tile) units than the
+    shared-slab kernel's four waves take (27 > 16: the per-attribute kernel runs instead) -- against the f64 chain."""
+    args = _setup(shape, 21 + shape[1], nrows=nrows, max_len=1000)
+    y_ref, dt_ref, dw_ref, db_ref = _reference(*args)
+    y, dt, dw, db = _run(*args, 0.0, 0, torch.bfloat16, cuda)
+    assert (y.double().cpu() - y_ref).abs().max().item() <= 2.0 ** -7 * max(1.0, y_ref.abs().max().item())
+    assert _rel(dw, dw_ref) < 6e-3 and _rel(db, db_ref) < 6e-3
+    for a, b in zip(dt, dt_ref):
+        assert _rel(a, b) < 6e-3
