@@ -38,8 +38,10 @@ __device__ __forceinline__ GeluK gelu_consts(float s) {
     return k;
 }
 // first half: the exponential (kept apart so that a kernel can split the work of one element over two phases)
+// (x x) c, in this order: two elements' worth is two packed multiplies (gelu_scaled2), where (x c) x compiled to four
+// scalar ones
 __device__ __forceinline__ float gelu_expterm(float x) {
-    return __builtin_amdgcn_exp2f((x * GELU_NEG_HALF_LOG2E) * x);
+    return __builtin_amdgcn_exp2f((x * x) * GELU_NEG_HALF_LOG2E);
 }
 // s * Phi(x) and s * (1/2 - e Q(|x|)) >= 0
 __device__ __forceinline__ void gelu_cdf(float x, float e, const GeluK& k, float& cdf, float& us) {
@@ -59,6 +61,29 @@ __device__ __forceinline__ void gelu_scaled(float x, const GeluK& k, float& y, f
     gelu_cdf(x, e, k, cdf, us);
     y = fmaf(fabsf(x), us, k.c0 * x);
     dy = fmaf(e * x, k.pdfc, cdf);
+}
+
+// two elements at once, written on 2-vectors so that hipcc emits v_pk_mul_f32 / v_pk_fma_f32 throughout; the same IEEE
+// operations in the same order as gelu_scaled, element by element (the elementwise kernels and the GEMM epilogues must
+// agree bit for bit)
+__device__ __forceinline__ void gelu_scaled2(f32x2 x, const GeluK& k, f32x2& y, f32x2& dy) {
+    const f32x2 u = (x * x) * GELU_NEG_HALF_LOG2E;
+    f32x2 e, a;
+    e[0] = __builtin_amdgcn_exp2f(u[0]);
+    e[1] = __builtin_amdgcn_exp2f(u[1]);
+    a[0] = fabsf(x[0]);
+    a[1] = fabsf(x[1]);
+    f32x2 q = __builtin_elementwise_fma(a, f32x2{k.c5, k.c5}, f32x2{k.c4, k.c4});
+    q = __builtin_elementwise_fma(a, q, f32x2{k.c3, k.c3});
+    q = __builtin_elementwise_fma(a, q, f32x2{k.c2, k.c2});
+    q = __builtin_elementwise_fma(a, q, f32x2{k.c1, k.c1});
+    q = __builtin_elementwise_fma(a, q, f32x2{k.c0, k.c0});
+    const f32x2 us = __builtin_elementwise_fma(-e, q, f32x2{k.c0, k.c0});
+    f32x2 cdf;
+    cdf[0] = k.c0 + copysignf(us[0], x[0]);
+    cdf[1] = k.c0 + copysignf(us[1], x[1]);
+    y = __builtin_elementwise_fma(a, us, x * k.c0);
+    dy = __builtin_elementwise_fma(e * x, f32x2{k.pdfc, k.pdfc}, cdf);
 }
 
 }  // namespace cwlt

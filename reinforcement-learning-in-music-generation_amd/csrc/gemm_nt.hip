@@ -214,37 +214,106 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
         if (seed_base) seed += *seed_base;   // device-resident offset: a captured hipGraph draws fresh masks per replay
         const GeluK gk = gelu_consts(keep_scale);
         const uint32_t thresh2 = thresh | (thresh << 16);
+        // Everything that depends on the row only through `erow + 16 i` is carried from row to row by additions: the two
+        // output addresses (+ 16 rows), the dropout key's pair index (+ 16 N / 2) and its first multiply
+        // ((lo + d) C = lo C + d C, exact mod 2^32) -- the row loop held a 64-bit multiply and three 32-bit ones per row
+        // for them, in a kernel whose epilogue instructions cost the neighbouring workgroup's main loop their time
+        // (DESIGN 4.2c).
+        // element index of (row, column) in the dense (M, N) activation: what cwlt_bias_gelu_dropout_fwd keys its mask
+        // with (the launcher insists on ldc == ldg == N).  The keep flags of dropout_mask<8>(seed, off, thresh), bit for
+        // bit: the four pair indices (off >> 1) + 0..3 share their upper word and key (off is a multiple of 8, so the low
+        // word does not carry), and (lo + j) * C = lo * C + j * C -- one 32-bit multiply instead of four in front of the
+        // four hashes; the two 16-bit halves of a hash word become two 16-bit lane masks that are ANDed onto the packed
+        // pair of bf16 results (no compare / select per element).
+        uint64_t pair = ((uint64_t)(m0 + erow) * (uint64_t)N + (uint64_t)(n0 + ecol)) >> 1;
+        const uint64_t pair_step = (uint64_t)N * 8;                                 // 16 rows of N elements, in pairs
+        uint32_t base = (uint32_t)pair * 0x9e3779b1u;
+        const uint32_t base_step = (uint32_t)pair_step * 0x9e3779b1u;
+        const uint32_t seed_key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9u);
+        bf16_t* pc = Cout + (m0 + erow) * ldc + n0 + ecol;
+        bf16_t* pg = G + (m0 + erow) * ldg + n0 + ecol;
+        const long cstep = 16 * ldc, gstep = 16 * ldg;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
+        for (int i = 0; i < 8; ++i, pair += pair_step, base += base_step, pc += cstep, pg += gstep) {
             const int row = erow + 16 * i;
             if (row < mrows) {
                 const uint4 hv = *reinterpret_cast<const uint4*>(et + row * LDE + ecol);
                 float t[8];
                 load8(reinterpret_cast<const bf16_t*>(&hv), t);
-                // element index of (row, column) in the dense (M, N) activation: what cwlt_bias_gelu_dropout_fwd keys
-                // its mask with (the launcher insists on ldc == ldg == N).  The keep flags of dropout_mask<8>(seed, off,
-                // thresh), bit for bit: the four pair indices (off >> 1) + 0..3 share their upper word and key (off is a
-                // multiple of 8, so the low word does not carry), and (lo + j) * C = lo * C + j * C -- one 32-bit multiply
-                // instead of four in front of the four hashes; the two 16-bit halves of a hash word become two 16-bit
-                // lane masks that are ANDed onto the packed pair of bf16 results (no compare / select per element).
-                const uint64_t pair0 = ((uint64_t)(m0 + row) * (uint64_t)N + (uint64_t)(n0 + ecol)) >> 1;
-                const uint32_t plo = (uint32_t)pair0, phi = (uint32_t)(pair0 >> 32);
-                const uint32_t key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9u) ^ (phi * 0x85ebca6bu);
-                const uint32_t base = plo * 0x9e3779b1u;
+                const uint32_t key = seed_key ^ ((uint32_t)(pair >> 32) * 0x85ebca6bu);
                 u32x4_t r, q;
+                // The four pairs of a chunk are worked on STAGE BY STAGE, not pair by pair: left alone the scheduler keeps
+                // live ranges short and emits each pair's chain of ~45 dependent instructions in one piece (a dependent
+                // VALU instruction issues every ~8 cycles, and two of a SIMD's four waves are in this loop); with the
+                // stages fenced every instruction has three independent ones between itself and its consumer.
+                uint32_t hw[4];
+                f32x2 xx[4], ee[4], aa[4], qq[4], us[4], yy[4], dd[4];
 #pragma unroll
-                for (int j = 0; j < 8; j += 2) {
-                    const uint32_t keep =
-                        keep_lanes16(hash32((base + (uint32_t)(j >> 1) * 0x9e3779b1u) ^ key), thresh2);
-                    float y0, d0, y1, d1;
-                    gelu_scaled(t[j] + b[j], gk, y0, d0);
-                    gelu_scaled(t[j + 1] + b[j + 1], gk, y1, d1);
-                    r[j >> 1] = f32x2_to_bf16x2(y0, y1) & keep;
-                    q[j >> 1] = f32x2_to_bf16x2(d0, d1) & keep;
+                for (int c = 0; c < 4; ++c) {
+                    hw[c] = (base + (uint32_t)c * 0x9e3779b1u) ^ key;
+                    xx[c] = f32x2{t[2 * c] + b[2 * c], t[2 * c + 1] + b[2 * c + 1]};
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hw[c] ^= hw[c] >> 16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ee[c] = (xx[c] * xx[c]) * GELU_NEG_HALF_LOG2E;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hw[c] *= 0x7feb352du;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    ee[c][0] = __builtin_amdgcn_exp2f(ee[c][0]);
+                    ee[c][1] = __builtin_amdgcn_exp2f(ee[c][1]);
+                    aa[c][0] = fabsf(xx[c][0]);
+                    aa[c][1] = fabsf(xx[c][1]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hw[c] ^= hw[c] >> 15;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qq[c] = __builtin_elementwise_fma(aa[c], f32x2{gk.c5, gk.c5}, f32x2{gk.c4, gk.c4});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hw[c] *= 0x846ca68bu;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qq[c] = __builtin_elementwise_fma(aa[c], qq[c], f32x2{gk.c3, gk.c3});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hw[c] ^= hw[c] >> 16;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qq[c] = __builtin_elementwise_fma(aa[c], qq[c], f32x2{gk.c2, gk.c2});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) hw[c] = keep_lanes16(hw[c], thresh2);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qq[c] = __builtin_elementwise_fma(aa[c], qq[c], f32x2{gk.c1, gk.c1});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) qq[c] = __builtin_elementwise_fma(aa[c], qq[c], f32x2{gk.c0, gk.c0});
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) us[c] = __builtin_elementwise_fma(-ee[c], qq[c], f32x2{gk.c0, gk.c0});
+#pragma unroll
+                for (int c = 0; c < 4; ++c) ee[c] = ee[c] * xx[c];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x2 cdf;
+                    cdf[0] = gk.c0 + copysignf(us[c][0], xx[c][0]);
+                    cdf[1] = gk.c0 + copysignf(us[c][1], xx[c][1]);
+                    dd[c] = __builtin_elementwise_fma(ee[c], f32x2{gk.pdfc, gk.pdfc}, cdf);
+                    yy[c] = __builtin_elementwise_fma(aa[c], us[c], xx[c] * gk.c0);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    r[c] = f32x2_to_bf16x2(yy[c][0], yy[c][1]) & hw[c];
+                    q[c] = f32x2_to_bf16x2(dd[c][0], dd[c][1]) & hw[c];
                 }
                 // g is the next GEMM's operand: default policy; gd waits for the backward: streamed past the caches
-                *reinterpret_cast<u32x4_t*>(Cout + (m0 + row) * ldc + n0 + ecol) = r;
-                u32x4_t* dst = reinterpret_cast<u32x4_t*>(G + (m0 + row) * ldg + n0 + ecol);
+                *reinterpret_cast<u32x4_t*>(pc) = r;
+                u32x4_t* dst = reinterpret_cast<u32x4_t*>(pg);
                 if (NT_STREAMS)
                     __builtin_nontemporal_store(q, dst);
                 else
@@ -262,8 +331,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     float cs[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) cs[j] = 0.f;
+    bf16_t* pc = Cout + (m0 + erow) * ldc + n0 + ecol;      // carried from row to row (+ 16 rows), as in the EPI_GELU branch
+    const long cstep = 16 * ldc;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 8; ++i, pc += cstep) {
         const int row = erow + 16 * i;
         const uint4 hv = *reinterpret_cast<const uint4*>(et + row * LDE + ecol);
         float t[8], gg[8];
@@ -280,7 +351,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
             r[1] = f32x2_to_bf16x2(t[2], t[3]);
             r[2] = f32x2_to_bf16x2(t[4], t[5]);
             r[3] = f32x2_to_bf16x2(t[6], t[7]);
-            u32x4_t* dst = reinterpret_cast<u32x4_t*>(Cout + (m0 + row) * ldc + n0 + ecol);
+            u32x4_t* dst = reinterpret_cast<u32x4_t*>(pc);
             if (NT_STREAMS)
                 __builtin_nontemporal_store(r, dst);
             else
