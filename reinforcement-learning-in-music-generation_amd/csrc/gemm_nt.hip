@@ -43,7 +43,7 @@ typedef __attribute__((address_space(3))) void lds_void;
 //             reaching HBM                                                                                  [FFN forward]
 enum { EPI_MUL = 0, EPI_GELU = 1 };
 
-template <int EPI, bool NT_STREAMS>
+template <int EPI, bool NT_STREAMS, bool ILV = true>
 __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
     const bf16_t* __restrict__ A, const bf16_t* __restrict__ W, bf16_t* G, bf16_t* __restrict__ Cout,
     float* __restrict__ part, long M, int N, int K, long lda, long ldw, long ldg, long ldc,
@@ -114,6 +114,28 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
                      : "v"(a_voff), "s"(ars), "s"(la), "s"(sk_), "v"(w_voff), "s"(wrs), "s"(sk2)                  \
                      : "memory", "scc");                                                                          \
     }
+    // the same three pieces one at a time (which = 0: the dy piece, 1 / 2: the two W pieces), for the main loop, where they
+    // are issued BETWEEN the step's MFMA groups: 24 pieces issued at once behind the barrier fill the texture-address FIFOs
+    // (SQ_VMEM_TA_ADDR_FIFO_FULL / _CMD_FIFO_FULL: a quarter of the CU-busy cycles, profiles/r03_ffn1_pmc.txt) and a wave
+    // that cannot issue its piece cannot issue the MFMAs behind it either
+#define GN_DMA1(stage, step, which)                                                                               \
+    {                                                                                                             \
+        unsigned keep;                                                                                            \
+        const uint32_t la = lds0 + (uint32_t)(stage) * STG + ((which) == 0 ? 0u : (which) == 1 ? 0x2000u : 0x4000u); \
+        const uint32_t sk_ = (uint32_t)(step) * (BK * 2) + ((which) == 2 ? w_half : 0u);                         \
+        if ((which) == 0)                                                                                         \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"                              \
+                         "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                         \
+                         : "=&s"(keep)                                                                            \
+                         : "v"(a_voff), "s"(ars), "s"(la), "s"(sk_)                                               \
+                         : "memory", "scc");                                                                      \
+        else                                                                                                      \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"                              \
+                         "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                         \
+                         : "=&s"(keep)                                                                            \
+                         : "v"(w_voff), "s"(wrs), "s"(la), "s"(sk_)                                               \
+                         : "memory", "scc");                                                                      \
+    }
     // fragment byte offsets of this lane inside a row block: row l31, chunk (2 ks + hf) at position ^ ((l31 >> 2) & 3)
     const int swz = (l31 >> 2) & 3;
     const int of0 = l31 * 64 + ((hf ^ swz) << 4), of1 = l31 * 64 + (((2 + hf) ^ swz) << 4);
@@ -134,6 +156,37 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x10, acc[0][1], 0, 0, 0);    \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w10, x11, acc[1][0], 0, 0, 0);    \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x11, acc[1][1], 0, 0, 0);    \
+    }
+
+    // a step with the next-but-one step's three pieces issued between its MFMA groups (more = false: no pieces)
+#define GN_COMPUTE_DMA(stage, nstage, nstepi, more)                                           \
+    {                                                                                         \
+        const char* sb = lds + (stage) * STG;                                                 \
+        {                                                                                     \
+            const bf16x8 w00 = GN_FRAG(sb + ow + of0), w01 = GN_FRAG(sb + ow + 2048 + of0);   \
+            const bf16x8 x00 = GN_FRAG(sb + oa + of0), x01 = GN_FRAG(sb + oa + 2048 + of0);   \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w00, x00, acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w01, x00, acc[0][1], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            if (more) GN_DMA1(nstage, nstepi, 0);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w00, x01, acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w01, x01, acc[1][1], 0, 0, 0); \
+        }                                                                                     \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        if (more) GN_DMA1(nstage, nstepi, 1);                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                    \
+        {                                                                                     \
+            const bf16x8 w10 = GN_FRAG(sb + ow + of1), w11 = GN_FRAG(sb + ow + 2048 + of1);   \
+            const bf16x8 x10 = GN_FRAG(sb + oa + of1), x11 = GN_FRAG(sb + oa + 2048 + of1);   \
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w10, x10, acc[0][0], 0, 0, 0); \
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x10, acc[0][1], 0, 0, 0); \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            if (more) GN_DMA1(nstage, nstepi, 2);                                             \
+            __builtin_amdgcn_sched_barrier(0);                                                \
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w10, x11, acc[1][0], 0, 0, 0); \
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w11, x11, acc[1][1], 0, 0, 0); \
+        }                                                                                     \
     }
 
     f32x16 acc[2][2];   // [row half i][column half j]: registers = columns (n), lanes = rows (m)
@@ -161,11 +214,17 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         const int st = s % NSTAGE;
-        if (s + 2 < nstep) GN_DMA((s + 2) % NSTAGE, s + 2);
-        GN_COMPUTE(st);
+        if (ILV) {
+            GN_COMPUTE_DMA(st, (s + 2) % NSTAGE, s + 2, s + 2 < nstep);
+        } else {
+            if (s + 2 < nstep) GN_DMA((s + 2) % NSTAGE, s + 2);
+            GN_COMPUTE(st);
+        }
     }
     __syncthreads();                                  // every wave is done with the ring: the epilogue tile reuses it
 #undef GN_DMA
+#undef GN_DMA1
+#undef GN_COMPUTE_DMA
 #undef GN_FRAG
 #undef GN_COMPUTE
 
@@ -378,6 +437,10 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
 }  // namespace gn
 }  // namespace cwlt
 
+static int interleave_dma() {   // CWLT_GEMM_NT_ILV=0: all of a step's pieces issued behind the barrier (A/B switch)
+    static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_ILV"); return (e && e[0] == '0') ? 0 : 1; }();
+    return v;
+}
 static int spread_starts() {   // CWLT_GEMM_NT_SPREAD=0: all workgroups start at once (A/B switch)
     static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_SPREAD"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
@@ -409,7 +472,9 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
     const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
     const long nblk = mt8 * (N / gn::TNC);
     static const bool nts = [] { const char* e = getenv("CWLT_GEMM_NT"); return !(e && e[0] == '0'); }();   // A/B switch
-    auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_MUL, true> : gn::gemm_nt_mul_kernel<gn::EPI_MUL, false>;
+    auto kfn = !interleave_dma() ? gn::gemm_nt_mul_kernel<gn::EPI_MUL, true, false>
+               : nts             ? gn::gemm_nt_mul_kernel<gn::EPI_MUL, true, true>
+                                 : gn::gemm_nt_mul_kernel<gn::EPI_MUL, false, true>;
     hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, st, (const bf16_t*)a, (const bf16_t*)w,
                        const_cast<bf16_t*>((const bf16_t*)g), (bf16_t*)c, part, (long)M, N, K, (long)lda, (long)ldw,
                        (long)ldg, (long)ldc, (const float*)nullptr, 0u, 1.0f, (uint64_t)0, (const uint64_t*)nullptr, spread_starts());
@@ -439,7 +504,9 @@ int cwlt_gemm_nt_bias_gelu_dropout(const void* a, const void* w, const float* bi
     const long mt8 = (mtiles + 7) / 8 * 8;
     const long nblk = mt8 * (N / gn::TNC);
     static const bool nts = [] { const char* e = getenv("CWLT_GEMM_NT"); return !(e && e[0] == '0'); }();
-    auto kfn = nts ? gn::gemm_nt_mul_kernel<gn::EPI_GELU, true> : gn::gemm_nt_mul_kernel<gn::EPI_GELU, false>;
+    auto kfn = !interleave_dma() ? gn::gemm_nt_mul_kernel<gn::EPI_GELU, true, false>
+               : nts             ? gn::gemm_nt_mul_kernel<gn::EPI_GELU, true, true>
+                                 : gn::gemm_nt_mul_kernel<gn::EPI_GELU, false, true>;
     hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
                        (bf16_t*)gd, (bf16_t*)g, (float*)nullptr, (long)M, N, K, (long)lda, (long)ldw, (long)N, (long)N,
                        bias, drop_thresh(p), drop_scale(p), seed, seed_base, spread_starts());
