@@ -51,7 +51,7 @@ __device__ __forceinline__ bf16x8 tfrag_at(const char* base) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool EDGE>
+template <bool EDGE, bool ILV = true>
 __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                       float* __restrict__ part, long M, int N1, int N2, long lda,
                                                       long ldb, long mslice) {
@@ -128,6 +128,24 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
                      : "v"(a_voff), "s"(ars), "s"(la), "s"(sa), "v"(b_voff), "s"(brs), "s"(sb_)                   \
                      : "memory", "scc");                                                                          \
     }
+    // one piece at a time (which = 0: A, 1: B), for issue between the step's MFMAs (see gemm_nt.hip, GN_COMPUTE_DMA)
+#define WG_DMA1(stage, step, which)                                                                               \
+    {                                                                                                             \
+        unsigned keep;                                                                                            \
+        const uint32_t la = lds0 + (uint32_t)(stage) * (2 * OPB) + ((which) ? 0x4000u : 0u);                      \
+        if (which)                                                                                                \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"                              \
+                         "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                         \
+                         : "=&s"(keep)                                                                            \
+                         : "v"(b_voff), "s"(brs), "s"(la), "s"((uint32_t)(step) * b_step)                         \
+                         : "memory", "scc");                                                                      \
+        else                                                                                                      \
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"                              \
+                         "buffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"                         \
+                         : "=&s"(keep)                                                                            \
+                         : "v"(a_voff), "s"(ars), "s"(la), "s"((uint32_t)(step) * a_step)                         \
+                         : "memory", "scc");                                                                      \
+    }
     // fragment read offsets of this lane inside a stage (k0 = 0; the second k-step adds 16 rows)
     const int oa0 = tfrag_off(64 * wn1, lane), oa1 = tfrag_off(64 * wn1 + 32, lane);
     const int ob0 = OPB + tfrag_off(64 * wn2, lane), ob1 = OPB + tfrag_off(64 * wn2 + 32, lane);
@@ -147,6 +165,30 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);   \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0_, d0_, acc[0][0], 0, 0, 0); \
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0_, d1_, acc[0][1], 0, 0, 0); \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1_, d0_, acc[1][0], 0, 0, 0); \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1_, d1_, acc[1][1], 0, 0, 0); \
+    }
+
+#define WG_COMPUTE_DMA(stage, nstage, nstepi)                                              \
+    {                                                                                      \
+        const char* sb = lds + (stage) * (2 * OPB);                                        \
+        constexpr int ko = 16 * ROW * 2;                                                   \
+        const bf16x8 a0 = tfrag_at(sb + oa0), b0 = tfrag_at(sb + ob0);                     \
+        const bf16x8 a1 = tfrag_at(sb + oa1), b1 = tfrag_at(sb + ob1);                     \
+        const bf16x8 c0_ = tfrag_at(sb + oa0 + ko), d0_ = tfrag_at(sb + ob0 + ko);         \
+        const bf16x8 c1_ = tfrag_at(sb + oa1 + ko), d1_ = tfrag_at(sb + ob1 + ko);         \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b0, acc[0][0], 0, 0, 0);   \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0, b1, acc[0][1], 0, 0, 0);   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        WG_DMA1(nstage, nstepi, 0);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b0, acc[1][0], 0, 0, 0);   \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b1, acc[1][1], 0, 0, 0);   \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0_, d0_, acc[0][0], 0, 0, 0); \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c0_, d1_, acc[0][1], 0, 0, 0); \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        WG_DMA1(nstage, nstepi, 1);                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
         acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1_, d0_, acc[1][0], 0, 0, 0); \
         acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(c1_, d1_, acc[1][1], 0, 0, 0); \
     }
@@ -173,11 +215,17 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        WG_DMA((s + 3) & 3, s + 3);
-        WG_COMPUTE(s & 3);
+        if (ILV) {
+            WG_COMPUTE_DMA(s & 3, (s + 3) & 3, s + 3);
+        } else {
+            WG_DMA((s + 3) & 3, s + 3);
+            WG_COMPUTE(s & 3);
+        }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // pieces still in flight target LDS: drain before exit
 #undef WG_DMA
+#undef WG_DMA1
+#undef WG_COMPUTE_DMA
 #undef WG_COMPUTE
     const int r0 = t1 * TM + 64 * wn1, c0 = t2 * TN + 64 * wn2 + l31;
     float* pb = part + ((long)slice * N1 + r0) * N2 + c0;
@@ -262,10 +310,21 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
         if (!e)
             e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<false>,
                                          hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (!e)
+            e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<true, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (!e)
+            e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<false, true>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e) return e;
         if (dev < 64) lds_set |= 1ull << dev;
     }
-    hipLaunchKernelGGL(edge ? wg::wgrad_kernel<true> : wg::wgrad_kernel<false>,
+    // the step's two pieces issued between its MFMAs instead of both behind the barrier (gemm_nt.hip, GN_COMPUTE_DMA):
+    // 1 009 / 956 / 291 / 847 -> 981 / 952 / 284 / 822 us on the four layer shapes, same box; CWLT_WGRAD_ILV=0: block issue
+    static const bool ilv = [] { const char* e = getenv("CWLT_WGRAD_ILV"); return !(e && e[0] == '0'); }();
+    auto kfn = ilv ? (edge ? wg::wgrad_kernel<true, true> : wg::wgrad_kernel<false, true>)
+                   : (edge ? wg::wgrad_kernel<true, false> : wg::wgrad_kernel<false, false>);
+    hipLaunchKernelGGL(kfn,
                        dim3(((N1 + 255) / 256) * ((N2 + 255) / 256) * S), dim3(1024), lds_bytes, st, (const bf16_t*)a,
                        (const bf16_t*)b, part, (long)M, N1, N2, (long)lda, (long)ldb, mslice);
     int e = (int)hipGetLastError();
