@@ -252,6 +252,36 @@ def ppo_report(args, ppo, world):
                        "select_pass": ppo.get("select_pass", "last-state")}}
 
 
+def run_ppo_block(run, group, nranks, device, log, *a, **kw):
+    """bench_ppo.run with the out-of-memory fallback: 16 rollouts x 30 states x window 1024 per update pass peak at
+    ~207 GB of the 288; should a box have less to give, the block is measured with half the rollouts per pass rather than
+    lost.  The retry happens OUTSIDE the except block (inside it the exception's traceback keeps the failed run's frames
+    -- models, rollout buffers -- alive, and nothing would be freed), and under data parallelism every rank takes the
+    same decision: the flag is all-reduced (MAX), so a rank that did fit retries with the smaller group as well (the
+    update passes hold collectives; ranks with different pass counts would hang)."""
+    import gc
+    while True:
+        oom = False
+        try:
+            res = run(*a, group=group, **kw)
+        except torch.OutOfMemoryError:
+            oom, res = True, None
+        if nranks > 1:
+            flag = torch.tensor([1.0 if oom else 0.0], device=device)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            oom = bool(flag.item() > 0)
+        if not oom:
+            return res, group
+        res = None
+        gc.collect()
+        if torch.cuda.is_available():
+            torch.cuda.empty_cache()
+        if group <= 1:
+            raise RuntimeError("ppo block: out of memory even at one rollout per update pass")
+        log("ppo block: out of memory at %d rollouts per update pass, measuring with %d" % (group, group // 2))
+        group //= 2
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1,
@@ -377,22 +407,9 @@ def main():
         import bench_ppo
         log("ppo block: %d rollouts x window %d, EPISODES %d, PPO_STEPS %d" % (args.ppo_rollouts, args.ppo_window, 30,
                                                                               args.ppo_steps))
-        ppo_group = PPO_GROUP
-        try:
-            ppo = bench_ppo.run(args.ppo_rollouts, args.ppo_window, 30, args.ppo_steps, iters=1, warmup=1,
-                                dtype=args.dtype, group=ppo_group, rank=rank, world=world, dev=dev, timer=True)
-        except torch.OutOfMemoryError:
-            # 16 rollouts x 30 states x window 1024 per update pass peak at ~207 GB of the 288; should a box have less to
-            # give, the block is measured with 8 per pass (~110 GB) rather than lost.  One rank alone cannot take this
-            # path (the passes hold collectives), so under data parallelism the error is left to propagate.
-            if world > 1:
-                raise
-            log("ppo block: out of memory at %d rollouts per update pass, measuring with %d" % (ppo_group, ppo_group // 2))
-            gc.collect()
-            torch.cuda.empty_cache()
-            ppo_group //= 2
-            ppo = bench_ppo.run(args.ppo_rollouts, args.ppo_window, 30, args.ppo_steps, iters=1, warmup=1,
-                                dtype=args.dtype, group=ppo_group, rank=rank, world=world, dev=dev, timer=True)
+        ppo, ppo_group = run_ppo_block(bench_ppo.run, PPO_GROUP, world, dev, log,
+                                       args.ppo_rollouts, args.ppo_window, 30, args.ppo_steps, iters=1, warmup=1,
+                                       dtype=args.dtype, rank=rank, world=world, dev=dev, timer=True)
         ppo["update_group"] = ppo_group
 
     if rank == 0:

@@ -195,6 +195,20 @@ int cwlt_gemm_nt_bias_dropout_add_layernorm(const void* a, const void* w, const 
                                             float* rstd, int64_t M, int N, int K, int64_t lda, int64_t ldw, float eps,
                                             float p, uint64_t seed, const uint64_t* seed_base, void* stream);
 
+/* ---- the dense projections: C (M, N) [+]= A (M, K) . W (N, K)^T [+ bias] -------------------------
+ * The `nn.Linear`s of fast_transformers' AttentionLayer / TransformerEncoderLayer (query / key / value / out projection,
+ * linear1, linear2: /root/reference/dqn_policy/model.py:128-137) and the six output heads as one projection
+ * (dqn_policy/model.py:156-161,241-249), forward and input-gradient forms -- what `torch.addmm / mm / addmm_` sent to
+ * hipBLASLt.  a (M, K), w (N, K), c (M, N) bf16 row-major with row strides lda, ldw, ldc; f32 accumulation; bias (N)
+ * f32 or NULL.  Forward: w = the layer's weight as stored.  Input gradient: w = the weight TRANSPOSED (dx = dy . W needs
+ * W's columns K-contiguous: pass w = W^T, (in, out) -> rows of length `out`); accumulate != 0 adds the product onto
+ * the bf16 values already in c (the residual gradient: `ds.addmm_(dh, W1)`).  256 x 256 tiles, LDS-DMA half-tile
+ * ring, v_mfma_f32_16x16x32_bf16 (csrc/gemm_bf16.hip).  N % 8 == 0, K % 64 == 0, K >= 128, strides multiples of 8,
+ * 16-byte aligned pointers.  cwlt_gemm_bf16_tune selects a schedule variant for A/B measurements (< 0: default). */
+int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int64_t lda,
+                   int64_t ldw, int64_t ldc, int accumulate, void* stream);
+int cwlt_gemm_bf16_tune(int variant);
+
 /* ---- positional encoding + dropout --------------------------------------------------------------
  * y = dropout_p(x + pe[r % T]) -- PositionalEncoding.forward, dqn_policy/model.py:90-92.  pe is the
  * registered (max_len, D) f32 buffer; pe == NULL gives plain dropout, which is also this op's

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -62,6 +62,8 @@ _SIGNATURES = {
     "cwlt_gemm_nt_bias_gelu_dropout": [_ptr] * 5 + [_c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_u64, _ptr, _ptr],
     "cwlt_gemm_nt_bias_dropout_add_layernorm": [_ptr] * 10 + [_c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_u64,
                                                 _ptr, _ptr],
+    "cwlt_gemm_bf16": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_gemm_bf16_tune": [_c_int],
     "cwlt_graph_replace_memset_nodes": [_ptr, _ptr],
     "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],

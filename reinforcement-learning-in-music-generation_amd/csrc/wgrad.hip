@@ -305,17 +305,12 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) dev = 0;
     if (dev >= 64 || !((lds_set >> dev) & 1ull)) {
-        int e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         lds_bytes);
-        if (!e)
-            e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<false>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (!e)
-            e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<true, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
-        if (!e)
-            e = (int)hipFuncSetAttribute((const void*)wg::wgrad_kernel<false, true>,
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        // all four instantiations (ILV defaults to true: <true> is <true, true>) -- CWLT_WGRAD_ILV=0 launches the other two
+        const void* kfns[4] = {(const void*)wg::wgrad_kernel<true, true>, (const void*)wg::wgrad_kernel<false, true>,
+                               (const void*)wg::wgrad_kernel<true, false>, (const void*)wg::wgrad_kernel<false, false>};
+        int e = 0;
+        for (int i = 0; i < 4 && !e; ++i)
+            e = (int)hipFuncSetAttribute(kfns[i], hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
         if (e) return e;
         if (dev < 64) lds_set |= 1ull << dev;
     }

@@ -145,7 +145,15 @@ def init_from_env():
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         backend = os.environ.get("CWLT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        import datetime
+        # explicit collective timeout (CWLT_DIST_TIMEOUT_S, default 10 min): a rank that died leaves the others in a
+        # collective; with the timeout they raise instead of hanging, exit non-zero, and the launcher tears the job down
+        kw = {"timeout": datetime.timedelta(seconds=float(os.environ.get("CWLT_DIST_TIMEOUT_S", "600")))}
         if torch.cuda.is_available():
             torch.cuda.set_device(local)
-        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+            if backend == "nccl":
+                # bind the RCCL communicator to THIS rank's GPU at creation (eager init; without it the first
+                # collective picks the device lazily and barrier() warns / may use device 0 for every rank)
+                kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return rank, local, world

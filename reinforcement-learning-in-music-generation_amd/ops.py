@@ -230,6 +230,15 @@ def capture_hip_graph(body, mode=torch.no_grad, name="step"):
     keep_graph: the hipGraph_t stays accessible after the capture so that its nodes can be counted and edited; the
     executable graph is instantiated by the first replay.  Should any memset node remain (inside a child graph), None
     is returned in place of the graph: the caller must run the step eagerly -- the capture itself executed nothing."""
+    import warnings
+    if not _graph_editing_available():
+        # a PyTorch without CUDAGraph(keep_graph=True) / raw_cuda_graph(): the graph's nodes can be neither counted nor
+        # rewritten, so nothing is captured and the caller runs the step eagerly (one warning per process)
+        if not _GRAPH_API[1]:
+            _GRAPH_API[1] = True
+            warnings.warn("capture_hip_graph: this PyTorch has no CUDAGraph(keep_graph=True).raw_cuda_graph(); "
+                          "hipGraph capture is off, steps run eagerly")
+        return None, None, {}, 0
     graph = torch.cuda.CUDAGraph(keep_graph=True)
     with torch.cuda.graph(graph), mode():
         out = body()
@@ -238,18 +247,38 @@ def capture_hip_graph(body, mode=torch.no_grad, name="step"):
     replaced = 0
     if census.get("memset", 0):
         n = ctypes.c_int(0)
-        _lib.check(_lib.load().cwlt_graph_replace_memset_nodes(ctypes.c_void_p(int(raw)), ctypes.byref(n)),
-                   "cwlt_graph_replace_memset_nodes")
+        st = _lib.load().cwlt_graph_replace_memset_nodes(ctypes.c_void_p(int(raw)), ctypes.byref(n))
         replaced = n.value
-        left = _lib.graph_node_census(raw).get("memset", 0)
+        left = -1 if st else _lib.graph_node_census(raw).get("memset", 0)
         if left:
-            import warnings
-            warnings.warn("capture_hip_graph: the captured %s still holds %d memset node(s) after the rewrite (%s); a "
-                          "replayed hipMemsetAsync is not reliable on this runtime -- running it eagerly instead"
-                          % (name, left, census))
+            # a rewrite that failed (status != 0: e.g. an element size the fill kernel does not take) or left a node
+            # inside a child graph: the step runs eagerly rather than raising out of a training loop
+            warnings.warn("capture_hip_graph: the captured %s %s (%s); a replayed hipMemsetAsync is not reliable on this "
+                          "runtime -- running it eagerly instead"
+                          % (name, "could not be rewritten (status %d)" % st if st
+                             else "still holds %d memset node(s) after the rewrite" % left, census))
             graph.reset()
             graph = None
     return graph, out, census, replaced
+
+
+_GRAPH_API = [None, False]          # [keep_graph / raw_cuda_graph available, warned]
+
+
+def _graph_editing_available():
+    if _GRAPH_API[0] is None:
+        try:
+            import inspect
+            ok = hasattr(torch.cuda.CUDAGraph, "raw_cuda_graph")
+            if ok:
+                try:
+                    ok = "keep_graph" in inspect.signature(torch.cuda.CUDAGraph.__new__).parameters
+                except (TypeError, ValueError):
+                    ok = True                      # signature not introspectable: trust the method's presence
+            _GRAPH_API[0] = bool(ok)
+        except Exception:
+            _GRAPH_API[0] = False
+    return _GRAPH_API[0]
 
 
 class GraphedCall:
@@ -618,6 +647,36 @@ def gelu_fwd(h, bias, p=0.0, seed=0, gd_inplace=False):
     _call("cwlt_bias_gelu_dropout_fwd", _lib.dev(h, "h"), _lib.opt(bias), _lib.dev(g), _lib.dev(h) if gd_inplace else None,
           rows, F, float(p), int(seed), _seed_base(), _lib.dtype_code(h.dtype), _lib.stream_ptr())
     return g
+
+
+# rows from which the hand-written projection GEMM is used (256-row tiles, one workgroup per CU: a step of a few
+# thousand token rows leaves most of the chip idle; those keep the library GEMM)
+GEMM_BF16_MIN_ROWS = int(os.environ.get("CWLT_GEMM_BF16_MIN_ROWS", 32768))
+GEMM_BF16 = os.environ.get("CWLT_GEMM_BF16", "1") != "0"
+
+
+def gemm_bf16_supported(a, w, c=None):
+    return (GEMM_BF16 and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2
+            and a.shape[1] == w.shape[1] and a.shape[1] % 64 == 0 and a.shape[1] >= 128 and w.shape[0] % 8 == 0
+            and a.shape[0] >= GEMM_BF16_MIN_ROWS
+            and all(t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in (a, w))
+            and (c is None or (c.dtype == torch.bfloat16 and c.shape == (a.shape[0], w.shape[0]) and c.stride(1) == 1
+                               and c.stride(0) % 8 == 0 and c.data_ptr() % 16 == 0)))
+
+
+def gemm_bf16(a, w, bias=None, out=None, accumulate=False):
+    """out (M, N) [+]= a (M, K) @ w (N, K).T [+ bias]: the projection GEMM (csrc/gemm_bf16.hip).  a, w bf16; bias (N)
+    f32 or None; out bf16 (allocated when None; accumulate adds onto its contents)."""
+    _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        if accumulate:
+            raise ValueError("gemm_bf16: accumulate needs the tensor to add onto")
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    _call("cwlt_gemm_bf16", _lib.dev(a, "a"), _lib.dev(w, "w"), _lib.opt(bias), _lib.dev(out, "out"), M, N, K, a.stride(0),
+          w.stride(0), out.stride(0), 1 if accumulate else 0, _lib.stream_ptr(), work=2.0 * M * N * K)
+    return out
 
 
 def gemm_nt_mul_supported(a, w, g):

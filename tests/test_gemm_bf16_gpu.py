@@ -1,0 +1,138 @@
+"""GPU: cwlt_gemm_bf16 -- the projection GEMM C (M, N) [+]= A (M, K) . W (N, K)^T [+ bias] of the encoder layer
+(query / key / value / out projection, linear1, linear2 and the six heads as one projection:
+/root/reference/dqn_policy/model.py:128-137,156-161,241-249) in its forward and input-gradient forms -- against the f64
+product of the same bf16 operands, at every shape the layer uses, with ragged row tiles, a partial column tile, strided
+operands, the accumulate form, every schedule variant, and at the bench's 524 288 rows.
+Tolerance: the result is ONE rounding of the f32 accumulator to bf16: 2^-8 x |value| + the f32 accumulation error, taken
+as 2^-7 x the largest |value| of the row block (as in test_ops_bf16_gpu.py)."""
+import pytest
+import torch
+
+import rlmg_amd  # noqa: F401
+from rlmg_amd import _lib, ops
+
+pytestmark = pytest.mark.gpu
+BF16_TOL = 2.0 ** -7
+
+
+@pytest.fixture(autouse=True)
+def _all_rows(monkeypatch):
+    monkeypatch.setattr(ops, "GEMM_BF16_MIN_ROWS", 0)
+    yield
+    _lib.load().cwlt_gemm_bf16_tune(-1)
+
+
+def _operands(M, N, K, seed, cuda, lda=None, ldw=None):
+    g = torch.Generator().manual_seed(seed)
+    a = torch.randn(M, lda or K, generator=g).bfloat16()[:, :K]
+    w = (torch.randn(N, ldw or K, generator=g) * (2.0 / K ** 0.5)).bfloat16()[:, :K]
+    bias = torch.randn(N, generator=g) * 0.3
+    c0 = torch.randn(M, N, generator=g).bfloat16()
+    return a, w, bias, c0
+
+
+def _check(out, ref):
+    sc = max(1.0, ref.abs().max().item())
+    err = (out.double().cpu() - ref).abs().max().item()
+    assert err <= BF16_TOL * sc, (err, sc)
+
+
+# the layer's shapes (N, K) x forms, at row counts that end inside a tile, inside a 16-row MFMA block, and on a boundary
+@pytest.mark.parametrize("M", [1, 255, 256, 1000, 4096 + 17])
+@pytest.mark.parametrize("N,K", [(1536, 512), (512, 2048), (512, 512), (2048, 512), (512, 1536), (384, 512)])
+def test_gemm_bf16_matches_the_f64_product(cuda, M, N, K):
+    a, w, bias, c0 = _operands(M, N, K, 7 * M + N + K, cuda)
+    ad, wd = a.to(cuda), w.to(cuda)
+    prod = a.double() @ w.double().t()
+    out = ops.gemm_bf16(ad, wd)
+    assert out.dtype == torch.bfloat16 and out.shape == (M, N)
+    _check(out, prod)
+    _check(ops.gemm_bf16(ad, wd, bias.to(cuda)), prod + bias.double())
+    acc = c0.to(cuda)
+    res = ops.gemm_bf16(ad, wd, out=acc, accumulate=True)
+    assert res.data_ptr() == acc.data_ptr()
+    _check(acc, prod + c0.double())
+    acc2 = c0.to(cuda)
+    ops.gemm_bf16(ad, wd, bias.to(cuda), out=acc2, accumulate=True)
+    _check(acc2, prod + c0.double() + bias.double())
+
+
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("K", [128, 192, 256, 320, 2048])
+def test_every_schedule_variant_and_short_reductions(cuda, variant, K):
+    """K = 128 is two K-tiles (the peeled tail alone), 192 / 320 an odd count: the slot parity and the counted waits of the
+    last two K-tiles are exercised at every length; all four DMA-depth / pre-read variants must agree with the f64 product."""
+    M, N = 777, 512
+    a, w, bias, _ = _operands(M, N, K, 100 + K, cuda)
+    _lib.load().cwlt_gemm_bf16_tune(variant)
+    out = ops.gemm_bf16(a.to(cuda), w.to(cuda), bias.to(cuda))
+    _check(out, a.double() @ w.double().t() + bias.double())
+
+
+def test_strided_operands_and_output_view(cuda):
+    """q / k / v are column blocks of the (R, 3 D) projection, the output may be a column block too: row strides are
+    arguments.  Everything outside the output view must be left untouched."""
+    M, N, K = 1500, 512, 512
+    a, w, bias, _ = _operands(M, N, K, 5, cuda, lda=3 * K, ldw=K + 64)
+    big_a = torch.zeros(M, 3 * K, device=cuda, dtype=torch.bfloat16)
+    big_a[:, K:2 * K] = a.to(cuda)
+    av = big_a[:, K:2 * K]
+    big_w = torch.zeros(N, K + 64, device=cuda, dtype=torch.bfloat16)
+    big_w[:, :K] = w.to(cuda)
+    wv = big_w[:, :K]
+    big_c = torch.full((M, 3 * N), 3.0, device=cuda, dtype=torch.bfloat16)
+    cv = big_c[:, N:2 * N]
+    assert av.stride(0) == 3 * K and wv.stride(0) == K + 64 and cv.stride(0) == 3 * N
+    ops.gemm_bf16(av, wv, bias.to(cuda), out=cv)
+    _check(cv, a.double() @ w.double().t() + bias.double())
+    assert torch.all(big_c[:, :N] == 3.0) and torch.all(big_c[:, 2 * N:] == 3.0)
+
+
+def test_exact_integers_and_an_asymmetric_weight(cuda):
+    """Small-integer operands make every product and sum exact: any swapped row / column or k-order mistake in the
+    fragment maps shows as a wrong integer (an identity-like A with an asymmetric W would hide nothing here)."""
+    M, N, K = 512, 512, 256
+    g = torch.Generator().manual_seed(11)
+    a = torch.randint(-3, 4, (M, K), generator=g).float()
+    w = torch.randint(-3, 4, (N, K), generator=g).float()
+    w[:, 0] = torch.arange(N).float() % 7 - 3        # column-dependent, not symmetric in (n, k)
+    out = ops.gemm_bf16(a.bfloat16().to(cuda), w.bfloat16().to(cuda))
+    ref = (a.double() @ w.double().t())
+    exact = ref.abs() <= 256                            # integers up to 256 are exact in bf16
+    assert torch.equal(out.double().cpu()[exact], ref[exact])
+
+
+def test_rejects_what_it_cannot_run(cuda):
+    a = torch.randn(256, 512, device=cuda).bfloat16()
+    w = torch.randn(512, 512, device=cuda).bfloat16()
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16(a[:, :96], w[:, :96])                       # K % 64
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16(a[:, :64], w[:, :64])                       # K < 128
+    with pytest.raises(RuntimeError):
+        ops.gemm_bf16(a, w[:508])                                  # N % 8
+    with pytest.raises(ValueError):
+        ops.gemm_bf16(a, w, accumulate=True)                       # nothing to add onto
+    assert not ops.gemm_bf16_supported(a.float(), w.float())
+
+
+def test_bench_rows(cuda):
+    """R = 524 288 (B = 512, T = 1024): the four (N, K) of the step, checked on three row slabs (first tile, a middle
+    XCD-dealt tile, the last rows) against the f64 product; accumulate form on linear1's input gradient."""
+    M = 524288
+    for N, K, acc in ((1536, 512, False), (512, 2048, True), (512, 512, False)):
+        g = torch.Generator(device=cuda).manual_seed(N + K)
+        a = torch.randn(M, K, device=cuda, generator=g).bfloat16()
+        w = (torch.randn(N, K, device=cuda, generator=g) * (2.0 / K ** 0.5)).bfloat16()
+        bias = torch.randn(N, device=cuda, generator=g) * 0.3
+        c0 = torch.randn(M, N, device=cuda, generator=g).bfloat16() if acc else None
+        out = c0.clone() if acc else None
+        out = ops.gemm_bf16(a, w, bias, out=out, accumulate=acc)
+        for lo in (0, 256 * 1031, M - 300):
+            sl = slice(lo, lo + 300)
+            ref = a[sl].double() @ w.double().t() + bias.double()
+            if acc:
+                ref = ref + c0[sl].double()
+            sc = max(1.0, ref.abs().max().item())
+            assert (out[sl].double() - ref).abs().max().item() <= BF16_TOL * sc
+        del a, w, out, c0
