@@ -204,10 +204,15 @@ int cwlt_gemm_nt_bias_dropout_add_layernorm(const void* a, const void* w, const 
  * W's columns K-contiguous: pass w = W^T, (in, out) -> rows of length `out`); accumulate != 0 adds the product onto
  * the bf16 values already in c (the residual gradient: `ds.addmm_(dh, W1)`).  256 x 256 tiles, LDS-DMA half-tile
  * ring, v_mfma_f32_16x16x32_bf16 (csrc/gemm_bf16.hip).  N % 8 == 0, K % 64 == 0, K >= 128, strides multiples of 8,
- * 16-byte aligned pointers.  cwlt_gemm_bf16_tune selects a schedule variant for A/B measurements (< 0: default). */
+ * 16-byte aligned pointers (N <= 8192 with a bias: the strip is kept in LDS).  Persistent: one workgroup per CU walks the
+ * tiles, the next tile's first operand pieces are requested before this tile's stores.
+ * cwlt_gemm_bf16_tune: schedule variant for A/B measurements (< 0: default; bit 0: DMA pieces issued at the end of the
+ * load segment, 5 half-tiles ahead, instead of between the MFMAs, 6 ahead); trace != NULL (8192 uint32 of device
+ * memory): bias-free, non-accumulating launches run the diagnostic build and leave workgroup 0's s_memtime stamps of
+ * its second tile there. */
 int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int64_t lda,
                    int64_t ldw, int64_t ldc, int accumulate, void* stream);
-int cwlt_gemm_bf16_tune(int variant);
+int cwlt_gemm_bf16_tune(int variant, void* trace);
 
 /* ---- positional encoding + dropout --------------------------------------------------------------
  * y = dropout_p(x + pe[r % T]) -- PositionalEncoding.forward, dqn_policy/model.py:90-92.  pe is the

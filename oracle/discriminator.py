@@ -24,17 +24,35 @@ def _embed_proj(sd, data):
     return F.linear(torch.cat(embs, -1), sd["proj.weight"], sd["proj.bias"])
 
 
-def airl_forward(sd, data, masks, n_layer, n_head, attention_window, bn_eps=1e-5):
-    """eval-mode forward of dqn_policy/AIRL_model.py::LongFormer -> (B, 1)."""
+def airl_forward(sd, data, masks, n_layer, n_head, attention_window, bn_eps=1e-5, batch_stats=False):
+    """forward of dqn_policy/AIRL_model.py::LongFormer -> (B, 1), dropout off.  batch_stats=False: eval mode
+    (BatchNorm1d on its running statistics).  batch_stats=True: BatchNorm1d on the statistics of THIS batch -- what
+    `RewardDiscri.all_forward` computes, which forces train() even while scoring (dqn_policy/AIRL.py:61-65)."""
     x = _embed_proj(sd, data)
     h = olf.longformer_forward(sd, x, masks, n_layer, n_head, attention_window // 2, prefix="longformer.")
     m = h.mean(dim=1)
     y = F.linear(m, sd["score_classifier.0.weight"], sd["score_classifier.0.bias"])
-    y = F.batch_norm(y, sd["score_classifier.1.running_mean"], sd["score_classifier.1.running_var"],
-                     sd["score_classifier.1.weight"], sd["score_classifier.1.bias"], False, 0.1, bn_eps)
+    if batch_stats:
+        y = F.batch_norm(y, None, None, sd["score_classifier.1.weight"], sd["score_classifier.1.bias"], True, 0.1, bn_eps)
+    else:
+        y = F.batch_norm(y, sd["score_classifier.1.running_mean"], sd["score_classifier.1.running_var"],
+                         sd["score_classifier.1.weight"], sd["score_classifier.1.bias"], False, 0.1, bn_eps)
     y = torch.tanh(y)
     y = torch.tanh(F.linear(y, sd["score_classifier.3.weight"], sd["score_classifier.3.bias"]))
     return torch.sigmoid(F.linear(y, sd["score_classifier.5.weight"], sd["score_classifier.5.bias"]))
+
+
+def calculate_reward(sd, states, mask_states, batch_size, n_layer, n_head, attention_window):
+    """dqn_policy/AIRL.py:69-91 `RewardDiscri.calculate_reward` with dropout off: the buffer is scored in consecutive
+    batches of `batch_size` through `all_forward` (train mode: BatchNorm on each batch's own statistics); a tail
+    shorter than a batch is never scored and keeps the initial 1.0."""
+    n = states.shape[0]
+    pred = torch.ones((n, 1))
+    for idx in range(n // batch_size):
+        s, e = idx * batch_size, (idx + 1) * batch_size
+        pred[s:e] = airl_forward(sd, states[s:e].long(), mask_states[s:e].long(), n_layer, n_head, attention_window,
+                                 batch_stats=True)
+    return pred
 
 
 def ppo_reward_forward(sd, data, masks, n_layer, n_head, attention_window):

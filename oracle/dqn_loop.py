@@ -126,3 +126,50 @@ def rollout(data_x, data_y, train_mask, choose_action, update_disc, update, num_
                                      'done': expert_done}
                 update(agent_transition, expert_transition, mask_next_states, True, epoch)
     return AgentBuffer, ExpertBuffer, gene_reward
+
+
+class RefDQN(object):
+    """`DQN` of IRL_dqn_train.py:210-345 on the oracle network, devices and logging stripped: two nets, Adam(1e-2),
+    MultiStepLR([20, 40], 0.1) stepped once per update, target sync when target_count % 50 == 0 (before the step),
+    loss = 0.3 * TD-MSE + 0.7 * CE of `train_step(agent_state, expert_next_state, mask)`.  Pinned by
+    tests/golden/dqn_rl_small.npz and dqn_loop_small.npz, both recorded from the reference's own class."""
+    Target_update, GAMMA, N_ACTIONS, init_lr = 50, 0.95, 25, 0.01
+
+    def __init__(self, eval_net, target_net):
+        from . import rl_math
+        self.rl_math = rl_math
+        self.eval_net, self.target_net = eval_net, target_net
+        self.optim = torch.optim.Adam(self.eval_net.parameters(), lr=self.init_lr)
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optim, milestones=[20, 40], gamma=0.1)
+        self.target_count = 0
+        self.cnt_update = 0
+        self.losses = []
+
+    def choose_action(self, x, target=None):
+        with torch.no_grad():
+            y = self.eval_net.forward_output(self.eval_net.forward_hidden(x))
+        return self.rl_math.dqn_choose_action(y, self.N_ACTIONS)
+
+    def update(self, agent_transition, expert_transition, mask_next_states, update_flag, epoch):
+        if self.target_count % self.Target_update == 0:
+            self.target_net.load_state_dict(self.eval_net.state_dict())
+        self.target_count += 1
+        expert_next_state = expert_transition['nextstate']
+        agent_state = agent_transition['state'].long()
+        agent_next_state = agent_transition['nextstate'].long()
+        agent_action = agent_transition['action'].long()
+        agent_reward = agent_transition['reward'].float()
+        agent_done = agent_transition['done'].long()
+        y = self.eval_net.forward_output(self.eval_net.forward_hidden(agent_state))
+        yt = self.target_net.forward_output(self.target_net.forward_hidden(agent_next_state))
+        MSEloss, _ = self.rl_math.dqn_td_loss(y, yt, agent_action, agent_reward, agent_done, self.GAMMA, self.N_ACTIONS)
+        CEloss = sum(self.eval_net.train_step(agent_state, expert_next_state, mask_next_states)) / 6
+        alpha = 0.3
+        total_loss = alpha * MSEloss + (1 - alpha) * CEloss
+        self.optim.zero_grad()
+        total_loss.backward()
+        self.optim.step()
+        self.scheduler.step()
+        self.cnt_update += 1
+        self.losses.append((MSEloss.item(), CEloss.item(), total_loss.item()))
+        return self.losses[-1]

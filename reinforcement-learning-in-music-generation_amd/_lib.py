@@ -63,7 +63,7 @@ _SIGNATURES = {
     "cwlt_gemm_nt_bias_dropout_add_layernorm": [_ptr] * 10 + [_c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_f32, _c_u64,
                                                 _ptr, _ptr],
     "cwlt_gemm_bf16": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_int, _ptr],
-    "cwlt_gemm_bf16_tune": [_c_int],
+    "cwlt_gemm_bf16_tune": [_c_int, _ptr],
     "cwlt_graph_replace_memset_nodes": [_ptr, _ptr],
     "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],

@@ -9,7 +9,8 @@
 // operands are K-contiguous and ONE kernel serves every projection; `accumulate` adds the product onto the residual
 // gradient already in C (what `ds.addmm_(dh, W1)` did through hipBLASLt).
 //
-// Structure (one 512-thread workgroup per CU, 256 x 256 output tile, BK = 64, v_mfma_f32_16x16x32_bf16):
+// Structure (PERSISTENT: one 512-thread workgroup per CU walks the 256 x 256 output tiles; BK = 64,
+// v_mfma_f32_16x16x32_bf16):
 //   * 8 waves as 2 (rows) x 4 (columns), each 128 x 64 of the tile = 32 accumulator tiles (128 registers);
 //   * operands go global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB per wave-instruction) in HALF-TILES of
 //     128 rows x 64 k (16 KiB): A rows-half 0, W columns-half 0, W columns-half 1, A rows-half 1 per K-tile, 8 slots =
@@ -17,13 +18,21 @@
 //     chunk position c ^ f(r) (applied on the SOURCE address, an LDS-DMA lands linearly) with f chosen so that the
 //     16-lane groups of a ds_read_b128 hit 16 different 16-byte bank slots: zero conflicts by construction
 //     (tools/probes/swizzle_search.py models the groups of MI355X_MICROARCH.md's LDS table);
-//   * a K-tile is 4 phases of {load segment: fragment reads + 2 DMA pieces + counted vmcnt | barrier | compute segment:
-//     16 MFMAs of one 64 x 32 quadrant x K = 64 | barrier}.  Waves 4-7 run ONE barrier behind waves 0-3, so on every
-//     SIMD (waves w and w + 4 share one) a wave in its compute segment sits beside a wave in its load segment:
-//     the matrix pipe always has a wave issuing, the LDS reads and DMA issue of the other are hidden behind it;
-//   * DMA pieces run D = 5 half-tiles ahead of their use and are never drained inside the loop: each load segment ends
-//     with `s_waitcnt vmcnt(2 (D - 2))`, which retires exactly the pieces the NEXT phase reads; a slot is rewritten
-//     at the earliest two phases after its last read (one phase for the staggered half, one for its reads to return);
+//   * a K-tile is 4 phases of {load segment: fragment reads, counted vmcnt | barrier | compute segment: 16 MFMAs of one
+//     64 x 32 quadrant x K = 64 | barrier}.  Waves 4-7 run ONE barrier behind waves 0-3, so on every SIMD (waves w and
+//     w + 4 share one) a wave in its compute segment sits beside a wave in its load segment: the matrix pipe always
+//     has a wave issuing, the LDS reads of the other are hidden behind it;
+//   * DMA pieces run D half-tiles ahead of their use and are never drained inside the loop: each load segment ends with
+//     a counted `s_waitcnt vmcnt`, which retires exactly the pieces the NEXT phase reads; a slot is rewritten at the
+//     earliest two phases after its last read (one phase for the staggered half, one for its reads to return).  The two
+//     pieces a wave issues per phase go out either at the end of its load segment (IC = false) or BETWEEN the MFMAs of
+//     its compute segment (IC = true: the four waves of a load segment otherwise queue their pieces at the CU's one
+//     texture-address path at the same moment, and the compute waves wait for them at the barrier);
+//   * the next tile's first D half-tiles are requested BEFORE this tile's epilogue, so the stores of one tile and the
+//     load latency of the next overlap; the stores are buffer stores (row / column edges by the hardware range check: no
+//     branch, always 16 per lane) so that the counted waits of the next tile can step over them (vmcnt counts loads,
+//     stores and LDS-DMA together, in issue order); the bias strip sits in LDS (a vector load in the epilogue would make
+//     the compiler drain the DMA pieces in flight);
 //   * the product is taken transposed (W rows on the MFMA's A operand) and the W rows of an MFMA tile are dealt so that a
 //     lane ends up with 8 CONSECUTIVE columns of one output row per pair of tiles: 16-byte stores straight from the
 //     accumulators, no LDS round trip in the epilogue.
@@ -37,13 +46,26 @@ namespace gb {
 constexpr int TM = 256, TN = 256, BK = 64;
 constexpr int HALF = 128 * BK * 2;              // bytes of a half-tile slot: 128 rows x 128 B = 16 KiB
 constexpr int NSLOT = 8;
+constexpr int RING = NSLOT * HALF;              // 128 KiB
+constexpr int EXTRA = 32768;                    // bias strip (N <= 8192 floats) / stamps of a trace build
+constexpr int MAXN_BIAS = EXTRA / 4;
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(3))) void lds_void;
 
-// two 1 KiB pieces (rows r0 .. r0 + 7 and r0 + 8 .. r0 + 15 of a slot) issued from inline asm so that the waits can be
-// counted by hand (through the builtin hipcc drains every piece in flight before the next LDS read); M0 carries the
-// LDS address
+// one 1 KiB piece (8 rows of a slot) issued from inline asm so that the waits can be counted by hand (through the
+// builtin hipcc drains every piece in flight before the next LDS read); M0 carries the LDS address
+#define GB_DMA1(v0, rs, la, so)                                                                        \
+    {                                                                                                  \
+        unsigned keep;                                                                                 \
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 4\n\t"                          \
+                     "buffer_load_dwordx4 %1, %2, %4 offen lds\n\t"                                    \
+                     "s_mov_b32 m0, %0"                                                                \
+                     : "=&s"(keep)                                                                     \
+                     : "v"(v0), "s"(rs), "s"(la), "s"(so)                                              \
+                     : "memory", "scc");                                                               \
+    }
+// the two pieces of a half-tile (rows r0 .. r0 + 7 and r0 + 8 .. r0 + 15 of the slot) back to back
 #define GB_DMA2(v0, v1, rs, la, so)                                                                    \
     {                                                                                                  \
         unsigned keep;                                                                                 \
@@ -58,39 +80,25 @@ typedef __attribute__((address_space(3))) void lds_void;
     }
 
 #define GB_FRAG(off) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (off)))
+#define GB_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-// EPI bits: 1 = bias, 2 = accumulate onto C
-template <int D, bool PF, int EPI>
+// EPI bits: 1 = bias, 2 = accumulate onto C.  TRACE: s_memtime stamps of one tile's segments (diagnostic build).
+template <int D, bool IC, int EPI, bool TRACE>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                             const float* __restrict__ bias, bf16_t* C, long M, int N,
-                                                            int K, long lda, long ldw, long ldc) {
-    __shared__ __attribute__((aligned(1024))) char lds[NSLOT * HALF];
+                                                            int K, long lda, long ldw, long ldc, int nblk,
+                                                            uint32_t* __restrict__ trace) {
+    static_assert((D == 5 && !IC) || (D == 6 && IC), "wait counts below are written for these two schedules");
+    __shared__ __attribute__((aligned(1024))) char lds[RING + EXTRA];
+    float* lds_bias = reinterpret_cast<float*>(lds + RING);
+    uint32_t* lds_trace = reinterpret_cast<uint32_t*>(lds + RING);
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = w >> 2, wn = w & 3;                 // wave tile: rows 128 wm .., columns 64 wn ..
     const int l15 = lane & 15, kg = lane >> 4;
     const int nt = (N + TN - 1) / TN;
-    const int xcd = blockIdx.x & 7, loc = blockIdx.x >> 3;
-    const long mt = (long)(loc / nt) * 8 + xcd;        // the column tiles of a row tile run on ONE XCD, back to back
-    const int ct = loc % nt;
-    const long m0 = mt * TM;
-    if (m0 >= M) return;
-    const int n0 = ct * TN;
-    const long mrows = min((long)TM, M - m0);
-    const int nrows = min(TN, N - n0);
-
-    // descriptors as four SGPRs each; rows past the tile's end read back as zeros (hardware range check)
-    const uint64_t abase = (uint64_t)(A + m0 * lda), wbase = (uint64_t)(W + (long)n0 * ldw);
-    u32x4_t ars, wrs;
-    ars[0] = __builtin_amdgcn_readfirstlane((uint32_t)abase);
-    ars[1] = __builtin_amdgcn_readfirstlane((uint32_t)(abase >> 32));
-    ars[2] = __builtin_amdgcn_readfirstlane((uint32_t)(((mrows - 1) * lda + K) * 2));
-    ars[3] = 0x00020000u;
-    wrs[0] = __builtin_amdgcn_readfirstlane((uint32_t)wbase);
-    wrs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(wbase >> 32));
-    wrs[2] = __builtin_amdgcn_readfirstlane((uint32_t)(((long)(nrows - 1) * ldw + K) * 2));
-    wrs[3] = 0x00020000u;
+    const int nK = K / BK;                             // >= 2 (launcher)
 
     // ---- DMA side.  Slot row r (0..127) of an A half mh is tile row 128 (r >> 6) + 64 mh + (r & 63), of a W half nh
     // tile column 64 (r >> 5) + 32 nh + (r & 31): every wave finds the rows of its quadrant in one slot.  This wave's
@@ -112,14 +120,24 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
     const uint32_t lds_w = (uint32_t)(uintptr_t)(lds_void*)lds + w * 2048;      // this wave's rows inside a slot
 
     // half-tile g = 4 t + j (j = 0: A half 0, 1: W half 0, 2: W half 1, 3: A half 1) lives in slot g & 7
+#define GB_LA(j, tp) (lds_w + (uint32_t)((((tp) & 1) * 4 + (j)) * HALF))
 #define GB_ISSUE(j, tp)                                                                   \
     {                                                                                     \
-        const uint32_t la = lds_w + (uint32_t)((((tp) & 1) * 4 + (j)) * HALF);            \
+        const uint32_t la = GB_LA(j, tp);                                                 \
         const uint32_t so = (uint32_t)(tp) * (BK * 2);                                    \
         if ((j) == 0) GB_DMA2(a_voff[0][0], a_voff[0][1], ars, la, so)                    \
         else if ((j) == 1) GB_DMA2(w_voff[0][0], w_voff[0][1], wrs, la, so)               \
         else if ((j) == 2) GB_DMA2(w_voff[1][0], w_voff[1][1], wrs, la, so)               \
         else GB_DMA2(a_voff[1][0], a_voff[1][1], ars, la, so)                             \
+    }
+#define GB_ISSUE1(j, tp, i)                                                               \
+    {                                                                                     \
+        const uint32_t la = GB_LA(j, tp) + (i) * 1024;                                    \
+        const uint32_t so = (uint32_t)(tp) * (BK * 2);                                    \
+        if ((j) == 0) GB_DMA1(a_voff[0][i], ars, la, so)                                  \
+        else if ((j) == 1) GB_DMA1(w_voff[0][i], wrs, la, so)                             \
+        else if ((j) == 2) GB_DMA1(w_voff[1][i], wrs, la, so)                             \
+        else GB_DMA1(a_voff[1][i], ars, la, so)                                           \
     }
 
     // ---- fragment side.  MFMA 16x16x32: lane l holds operand row l & 15, k = 8 (l >> 4) + j of a 32-wide k-step.
@@ -134,17 +152,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         a_off[k] = (64 * wm + l15) * 128 + pos;
         w_off[k] = (32 * wn + 8 * (l15 >> 2) + (l15 & 3)) * 128 + pos;
     }
-    // slot offsets of the current K-tile's buffer, toggled every K-tile
-    int bufo = 0;
-
-    f32x4 acc[4][8];               // [column tile nb][row tile mb]
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     bf16x8 AF[4][2], WF0[2][2], WF1[2][2], AN[4];
+    f32x4 acc[4][8];               // [column tile nb][row tile mb]
+    int bufo = 0;                  // slot offset of the current K-tile's buffer, toggled every K-tile
+    int tq = 0;                    // trace: stamp index
 
+#define GB_STAMP()                                                                         \
+    if (TRACE && tracing) {                                                                \
+        const uint32_t now_ = (uint32_t)__builtin_amdgcn_s_memtime();                      \
+        if (lane == 0) lds_trace[w * 1024 + (tq & 1023)] = now_;                           \
+        ++tq;                                                                              \
+    }
 #define GB_READ_A(dst, mh, k)                                                              \
     _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                    \
         dst[mb_][k] = GB_FRAG(bufo + ((mh) ? 3 : 0) * HALF + a_off[k] + mb_ * 2048);
@@ -155,195 +174,340 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
     _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                       \
         _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                   \
             dst[b_][k_] = GB_FRAG(bufo + (1 + (nh)) * HALF + w_off[k_] + b_ * 512);
-#define GB_MFMA(WF, mh, nh)                                                                \
-    _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                       \
-        _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                   \
-            _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                            \
-                acc[2 * (nh) + b_][4 * (mh) + mb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16( \
-                    WF[b_][k_], AF[mb_][k_], acc[2 * (nh) + b_][4 * (mh) + mb_], 0, 0, 0);
+#define GB_MFMA4(WF, mh, nh, b_, k_)                                                       \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                    \
+        acc[2 * (nh) + (b_)][4 * (mh) + mb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
+            WF[b_][k_], AF[mb_][k_], acc[2 * (nh) + (b_)][4 * (mh) + mb_], 0, 0, 0);
 
-    // end of a load segment: DMA issue, counted wait, barrier; then the compute segment between two barriers
-#define GB_MID(issue, j, tp, vm)                                                           \
+    // end of a load segment: [IC = false: DMA issue,] counted wait, barrier; then the compute segment -- 16 MFMAs,
+    // IC = true: with the phase's two pieces behind the 4th and the 12th -- and the closing barrier
+#define GB_PHASE(WF, mh, nh, issue, j, tp, vm)                                             \
     __builtin_amdgcn_sched_barrier(0);                                                     \
-    if (issue) GB_ISSUE(j, tp)                                                             \
-    asm volatile("s_waitcnt vmcnt(" #vm ")" ::: "memory");                                 \
+    if (!IC && (issue)) GB_ISSUE(j, tp)                                                    \
+    GB_WAIT(vm);                                                                           \
     __builtin_amdgcn_s_barrier();                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
-    __builtin_amdgcn_s_setprio(1);
-#define GB_END                                                                             \
+    GB_STAMP()                                                                             \
+    __builtin_amdgcn_s_setprio(1);                                                         \
+    GB_MFMA4(WF, mh, nh, 0, 0)                                                             \
+    if (IC && (issue)) {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        GB_ISSUE1(j, tp, 0)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }                                                                                      \
+    GB_MFMA4(WF, mh, nh, 1, 0)                                                             \
+    GB_MFMA4(WF, mh, nh, 0, 1)                                                             \
+    if (IC && (issue)) {                                                                   \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        GB_ISSUE1(j, tp, 1)                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }                                                                                      \
+    GB_MFMA4(WF, mh, nh, 1, 1)                                                             \
     __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     __builtin_amdgcn_s_barrier();                                                          \
-    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_sched_barrier(0);                                                     \
+    GB_STAMP()
 
     // One K-tile.  i1..i4: whether phase p still issues a half-tile (g = 4 t + p - 1 + D < 4 nK); v1..v4: the counted
-    // waits (steady state 2 (D - 2)); last: no next K-tile to pre-read from.
+    // waits; last: no next K-tile to pre-read from.
 #define GB_KTILE(t, i1, i2, i3, i4, v1, v2, v3, v4, last)                                                  \
     {                                                                                                      \
-        /* phase 1: quadrant (rows half 0, columns half 0) */                                              \
-        if (PF) {                                                                                          \
-            _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) AF[mb_][0] = AN[mb_];                      \
-        } else {                                                                                           \
-            GB_READ_A(AF, 0, 0)                                                                            \
-        }                                                                                                  \
+        /* phase 1: quadrant (rows half 0, columns half 0); its k-step 0 A fragments were read a phase ago */ \
+        _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) AF[mb_][0] = AN[mb_];                          \
         GB_READ_A(AF, 0, 1)                                                                                \
         GB_READ_W(WF0, 0)                                                                                  \
-        GB_MID(i1, (D + 0) & 3, (t) + ((D + 0) >> 2), v1)                                                  \
-        GB_MFMA(WF0, 0, 0)                                                                                 \
-        GB_END                                                                                             \
+        GB_PHASE(WF0, 0, 0, i1, (D + 0) & 3, (t) + ((D + 0) >> 2), v1)                                     \
         /* phase 2: (rows half 0, columns half 1) */                                                       \
         GB_READ_W(WF1, 1)                                                                                  \
-        GB_MID(i2, (D + 1) & 3, (t) + ((D + 1) >> 2), v2)                                                  \
-        GB_MFMA(WF1, 0, 1)                                                                                 \
-        GB_END                                                                                             \
+        GB_PHASE(WF1, 0, 1, i2, (D + 1) & 3, (t) + ((D + 1) >> 2), v2)                                     \
         /* phase 3: (rows half 1, columns half 1) */                                                       \
         GB_READ_A(AF, 1, 0)                                                                                \
         GB_READ_A(AF, 1, 1)                                                                                \
-        GB_MID(i3, (D + 2) & 3, (t) + ((D + 2) >> 2), v3)                                                  \
-        GB_MFMA(WF1, 1, 1)                                                                                 \
-        GB_END                                                                                             \
+        GB_PHASE(WF1, 1, 1, i3, (D + 2) & 3, (t) + ((D + 2) >> 2), v3)                                     \
         /* phase 4: (rows half 1, columns half 0); W half 0 is still in registers */                       \
-        if (PF && !(last)) { GB_READ_AN(bufo ^ (4 * HALF)) }                                               \
-        GB_MID(i4, (D + 3) & 3, (t) + ((D + 3) >> 2), v4)                                                  \
-        GB_MFMA(WF0, 1, 0)                                                                                 \
-        GB_END                                                                                             \
+        if (!(last)) { GB_READ_AN(bufo ^ (4 * HALF)) }                                                     \
+        GB_PHASE(WF0, 1, 0, i4, (D + 3) & 3, (t) + ((D + 3) >> 2), v4)                                     \
         bufo ^= 4 * HALF;                                                                                  \
     }
 
-    const int nK = K / BK;                                  // >= 2 (launcher)
-    // prologue: half-tiles 0 .. D - 1, then the first two have landed everywhere
-#pragma unroll
-    for (int g = 0; g < D; ++g) GB_ISSUE(g & 3, g >> 2)
-    if (D == 5)
-        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_sched_barrier(0);
-    if (PF) { GB_READ_AN(0) }
-    if (wm) __builtin_amdgcn_s_barrier();                   // waves 4-7 run one barrier behind waves 0-3
-    __builtin_amdgcn_sched_barrier(0);
+    // Counted waits (S = steady state).  With the pieces issued at the END of the load segment (IC = false) the wait
+    // of phase P leaves D - 2 half-tiles in flight; issued inside the compute segment (IC = true) they are one phase
+    // younger and D - 3 are left: 2 x 3 = 6 pieces for both schedules built.  In the FIRST K-tile of a tile the 16
+    // stores of the previous tile's epilogue sit in the queue behind the D prologue half-tiles: while the half-tile a
+    // phase waits for (P + 1) is one of those (P <= D - 2) the stores are allowed to stay outstanding as well (+ 16).
+    constexpr int S = 6, SF = S + 16;
 
-    int t = 0;
-    if (D == 5) {
-        for (; t < nK - 2; ++t) GB_KTILE(t, true, true, true, true, 6, 6, 6, 6, false)
-        // the last two K-tiles: phase P of G = 4 nK issues while P <= G - D, then waits 2 max(0, G - P - 2)
-        GB_KTILE(t, true, true, true, false, 6, 6, 6, 4, false)
-        ++t;
-        GB_KTILE(t, false, false, false, false, 2, 0, 0, 0, true)
-    } else {
-        for (; t < nK - 2; ++t) GB_KTILE(t, true, true, true, true, 8, 8, 8, 8, false)
-        GB_KTILE(t, true, true, false, false, 8, 8, 6, 4, false)
-        ++t;
-        GB_KTILE(t, false, false, false, false, 2, 0, 0, 0, true)
+    // bias strip -> LDS, once per workgroup (read back in every epilogue without touching the vector-memory queue)
+    if (EPI & 1) {
+        for (int i = tid; i < N; i += 512) lds_bias[i] = bias[i];
     }
-    if (!wm) __builtin_amdgcn_s_barrier();                  // every wave has passed the same number of barriers
+
+    u32x4_t ars, wrs;
+    ars[3] = 0x00020000u;
+    wrs[3] = 0x00020000u;
+    // tile index -> (row tile, column tile): ids are dealt round-robin over the 8 XCDs, the column tiles of a row tile
+    // run on ONE XCD, back to back (the second finds the A strip in that XCD's L2)
+#define GB_TILE(idx, m0_, n0_)                                                             \
+    const int xcd_ = (idx) & 7, loc_ = (idx) >> 3;                                         \
+    const long m0_ = ((long)(loc_ / nt) * 8 + xcd_) * TM;                                  \
+    const int n0_ = (loc_ % nt) * TN;
+    // descriptors as four SGPRs each; rows past the tile's end read back as zeros (hardware range check)
+#define GB_DESC(m0_, n0_)                                                                                   \
+    {                                                                                                       \
+        const long mr_ = min((long)TM, M - (m0_));                                                          \
+        const int nr_ = min(TN, N - (n0_));                                                                 \
+        const uint64_t ab_ = (uint64_t)(A + (m0_) * lda), wb_ = (uint64_t)(W + (long)(n0_) * ldw);          \
+        ars[0] = __builtin_amdgcn_readfirstlane((uint32_t)ab_);                                             \
+        ars[1] = __builtin_amdgcn_readfirstlane((uint32_t)(ab_ >> 32));                                     \
+        ars[2] = __builtin_amdgcn_readfirstlane((uint32_t)(((mr_ - 1) * lda + K) * 2));                     \
+        wrs[0] = __builtin_amdgcn_readfirstlane((uint32_t)wb_);                                             \
+        wrs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(wb_ >> 32));                                     \
+        wrs[2] = __builtin_amdgcn_readfirstlane((uint32_t)(((long)(nr_ - 1) * ldw + K) * 2));               \
+    }
+#define GB_PROLOGUE()                                                                      \
+    _Pragma("unroll") for (int g = 0; g < D; ++g) GB_ISSUE(g & 3, g >> 2)
+
+    int idx = blockIdx.x;
+    while (idx < nblk) {           // padding tiles (row tiles are dealt in eights) hold no rows
+        GB_TILE(idx, mc_, nc_)
+        if (mc_ < M) break;
+        idx += gridDim.x;
+    }
+    if (idx >= nblk) return;
+    {
+        GB_TILE(idx, m0p, n0p)
+        GB_DESC(m0p, n0p)
+        __syncthreads();           // the bias strip is in LDS (and its loads are behind us)
+        GB_PROLOGUE()
+    }
+    bool first = true;
+    int it = 0;
+    while (true) {
+        GB_TILE(idx, m0, n0)
+        const bool tracing = TRACE && blockIdx.x == 0 && it == 1;
+        GB_STAMP()
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bufo = 0;
+        // half-tiles 0 and 1 have landed everywhere.  A workgroup's first tile has no stores in the queue: it drains
+        // its prologue once, after which the "+ 16" waits of the first K-tile hold trivially
+        if (first) {
+            GB_WAIT(0);
+        } else {
+            GB_WAIT(2 * (D - 2) + 16);
+        }
+        first = false;
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        GB_STAMP()
+        GB_READ_AN(0)
+        if (wm) __builtin_amdgcn_s_barrier();               // waves 4-7 run one barrier behind waves 0-3
+        __builtin_amdgcn_sched_barrier(0);
+
+        // phase P of G = 4 nK issues while P <= G - D; the waits of the last phases shrink with what is left in flight
+        if (nK == 2) {
+            if (D == 5) {
+                GB_KTILE(0, true, true, true, false, SF, SF, SF, 4, false)
+            } else {
+                GB_KTILE(0, true, true, false, false, SF, SF, SF, 4 + 16, false)
+            }
+            GB_KTILE(1, false, false, false, false, 2, 0, 0, 0, true)
+        } else {
+            int t = 0;
+            if (D == 5) {
+                GB_KTILE(t, true, true, true, true, SF, SF, SF, S, false)
+                for (t = 1; t < nK - 2; ++t) GB_KTILE(t, true, true, true, true, S, S, S, S, false)
+                GB_KTILE(t, true, true, true, false, S, S, S, 4, false)
+            } else {
+                GB_KTILE(t, true, true, true, true, SF, SF, SF, SF, false)
+                for (t = 1; t < nK - 2; ++t) GB_KTILE(t, true, true, true, true, S, S, S, S, false)
+                GB_KTILE(t, true, true, false, false, S, S, S, 4, false)
+            }
+            ++t;
+            GB_KTILE(t, false, false, false, false, 2, 0, 0, 0, true)
+        }
+        if (!wm) __builtin_amdgcn_s_barrier();              // every wave has passed the same number of barriers
+        __builtin_amdgcn_sched_barrier(0);
+        GB_STAMP()
+
+        // ---- the next tile of this workgroup: its first D half-tiles go out now (every LDS read of this tile is done)
+        int nxt = idx + gridDim.x;
+        while (nxt < nblk) {
+            GB_TILE(nxt, mc_, nc_)
+            if (mc_ < M) break;
+            nxt += gridDim.x;
+        }
+        // ---- epilogue: lane (l15, kg) holds, for row tile mb and column half q, the 8 columns 32 q + 8 kg .. + 7 of
+        // row 16 mb + l15 of its wave tile: registers 0-3 of acc[2 q][mb] then of acc[2 q + 1][mb].  Buffer stores:
+        // rows past the end fall outside the descriptor, columns past the end get an offset outside it.
+        const long mrows = min((long)TM, M - m0);
+        const int ncols = min(TN, N - n0);
+        const __amdgpu_buffer_rsrc_t crs = make_rsrc(C + m0 * ldc + n0, (uint32_t)(((mrows - 1) * ldc + ncols) * 2));
+        uint32_t c_voff[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int col = 64 * wn + 32 * q + 8 * kg;
+            c_voff[q] = col < ncols ? ((uint32_t)(128 * wm + l15) * (uint32_t)ldc + col) * 2 : 0x7ffffff0u;
+        }
+        const uint32_t c_step = (uint32_t)(16 * ldc * 2);
+        u32x4_t cin[8][2];
+        if (EPI & 2) {
+            // the residual gradient this product is added onto: requested first, waited for by hand (the compiler's
+            // own counted waits do not know about the DMA pieces in the queue), then the next tile's prologue
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+                    cin[mb][q] = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)(c_voff[q] + mb * c_step), 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 8; mb += 2)
+                asm volatile("s_waitcnt vmcnt(0)"
+                             : "+v"(cin[mb][0]), "+v"(cin[mb][1]), "+v"(cin[mb + 1][0]), "+v"(cin[mb + 1][1])::"memory");
+        }
+        if (nxt < nblk) {
+            GB_TILE(nxt, m0n, n0n)
+            GB_DESC(m0n, n0n)
+            GB_PROLOGUE()
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        GB_STAMP()
+        float bs[2][8];
+        if (EPI & 1) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const int col = n0 + 64 * wn + 32 * q + 8 * kg;
+                const int cc = col < N ? col : 0;            // the strip holds N floats
+                const float4 b0 = *reinterpret_cast<const float4*>(lds_bias + cc);
+                const float4 b1 = *reinterpret_cast<const float4*>(lds_bias + cc + 4);
+                bs[q][0] = b0.x; bs[q][1] = b0.y; bs[q][2] = b0.z; bs[q][3] = b0.w;
+                bs[q][4] = b1.x; bs[q][5] = b1.y; bs[q][6] = b1.z; bs[q][7] = b1.w;
+            }
+        }
+#pragma unroll
+        for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                float v[8];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v[r] = acc[2 * q][mb][r];
+                    v[4 + r] = acc[2 * q + 1][mb][r];
+                }
+                if (EPI & 2) {
+                    float o[8];
+                    load8(reinterpret_cast<const bf16_t*>(&cin[mb][q]), o);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += o[j];
+                }
+                if (EPI & 1) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] += bs[q][j];
+                }
+                u32x4_t pk;
+                pk[0] = f32x2_to_bf16x2(v[0], v[1]);
+                pk[1] = f32x2_to_bf16x2(v[2], v[3]);
+                pk[2] = f32x2_to_bf16x2(v[4], v[5]);
+                pk[3] = f32x2_to_bf16x2(v[6], v[7]);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, crs, (int)(c_voff[q] + mb * c_step), 0, 0);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        GB_STAMP()
+        if (nxt >= nblk) break;
+        idx = nxt;
+        ++it;
+    }
+    if (TRACE && blockIdx.x == 0) {
+        __syncthreads();
+        for (int i = tid; i < 8 * 1024; i += 512) trace[i] = lds_trace[i];
+    }
 #undef GB_KTILE
-#undef GB_MID
-#undef GB_END
-#undef GB_MFMA
+#undef GB_PHASE
+#undef GB_MFMA4
 #undef GB_READ_W
 #undef GB_READ_A
 #undef GB_READ_AN
 #undef GB_ISSUE
-
-    // ---- epilogue: lane (l15, kg) holds, for row tile mb and column half q, the 8 columns 32 q + 8 kg .. + 7 of row
-    // 16 mb + l15 of its wave tile: registers 0-3 of acc[2 q][mb] then of acc[2 q + 1][mb]
-    float bs[2][8];
-    if (EPI & 1) {
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int col = n0 + 64 * wn + 32 * q + 8 * kg;
-            if (col < N) {
-                loadf<8>(bias + col, bs[q]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) bs[q][j] = 0.f;
-            }
-        }
-    }
-#pragma unroll
-    for (int mb = 0; mb < 8; ++mb) {
-        const long row = m0 + 128 * wm + 16 * mb + l15;
-        if (row < M) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const int col = n0 + 64 * wn + 32 * q + 8 * kg;
-                if (col < N) {
-                    float v[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        v[r] = acc[2 * q][mb][r];
-                        v[4 + r] = acc[2 * q + 1][mb][r];
-                    }
-                    bf16_t* dst = C + row * ldc + col;
-                    if (EPI & 2) {
-                        float o[8];
-                        load8(dst, o);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += o[j];
-                    }
-                    if (EPI & 1) {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] += bs[q][j];
-                    }
-                    store8(dst, v);
-                }
-            }
-        }
-    }
+#undef GB_ISSUE1
+#undef GB_LA
+#undef GB_TILE
+#undef GB_DESC
+#undef GB_PROLOGUE
+#undef GB_STAMP
 }
 
 }  // namespace gb
 }  // namespace cwlt
 
-static int g_variant = -1;      // -1: default; bit 0: D = 6 instead of 5; bit 1: no pre-read of the next K-tile
+static int g_variant = -1;      // -1: default; bit 0: the other schedule
+static uint32_t* g_trace = nullptr;
 
 extern "C" {
 
-/* Tuning switch for A/B measurements (tools/bench_gemm.py): variant < 0 restores the default. */
-int cwlt_gemm_bf16_tune(int variant) {
+/* Tuning switch for A/B measurements (tools/bench_gemm.py): bit 0 selects the other DMA schedule (pieces issued at the
+ * end of the load segment, 5 half-tiles ahead, instead of between the MFMAs, 6 ahead); variant < 0 restores the default.
+ * trace != NULL (8192 uint32 of device memory): the next bias-free, non-accumulating launches run the diagnostic build,
+ * which leaves the s_memtime stamps of workgroup 0's second tile there (8 waves x 1024). */
+int cwlt_gemm_bf16_tune(int variant, void* trace) {
     g_variant = variant;
+    g_trace = (uint32_t*)trace;
     return CWLT_OK;
 }
 
 /* c (M, N) [+]= a (M, K) . w (N, K)^T [+ bias (N) f32]: bf16 operands and result, f32 accumulation.
- * N % 8 == 0, K % 64 == 0, K >= 128, row strides multiples of 8 elements, 16-byte aligned pointers;
- * accumulate != 0: the product (and bias) is added onto the bf16 values already in c. */
+ * N % 8 == 0 (N <= 8192 with a bias), K % 64 == 0, K >= 128, row strides multiples of 8 elements, 16-byte aligned
+ * pointers; accumulate != 0: the product (and bias) is added onto the bf16 values already in c. */
 int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int64_t lda,
                    int64_t ldw, int64_t ldc, int accumulate, void* stream) {
     using namespace cwlt;
     if (M < 0 || N <= 0 || K < 128 || (N % 8) || (K % 64)) return CWLT_ERR_ARG;
+    if (bias && N > gb::MAXN_BIAS) return CWLT_ERR_ARG;
     if (M == 0) return CWLT_OK;
     if (!a || !w || !c) return CWLT_ERR_ARG;
     if (((lda | ldw | ldc) & 7) || lda < K || ldw < K || ldc < N) return CWLT_ERR_ARG;
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)c | (uintptr_t)bias) & 15) return CWLT_ERR_ARG;
     /* byte offsets inside one row tile / one weight strip are 32-bit (buffer resources); tile bases are 64-bit */
-    if ((int64_t)gb::TM * lda * 2 >= (1ll << 31) || (int64_t)gb::TN * ldw * 2 >= (1ll << 31)) return CWLT_ERR_ARG;
+    if ((int64_t)gb::TM * lda * 2 >= (1ll << 31) || (int64_t)gb::TN * ldw * 2 >= (1ll << 31) ||
+        (int64_t)gb::TM * ldc * 2 >= (1ll << 30))
+        return CWLT_ERR_ARG;
     const long mtiles = (M + gb::TM - 1) / gb::TM;
     const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
     const long nblk = mt8 * ((N + gb::TN - 1) / gb::TN);
-    if (nblk >= (1ll << 31)) return CWLT_ERR_ARG;
+    if (nblk >= (1ll << 30)) return CWLT_ERR_ARG;
+    // one workgroup per CU (128 KiB of LDS, 256 registers x 8 waves), in multiples of 8 so that a workgroup's tiles
+    // stay on its XCD's share of the tile order
+    static int ncu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!ncu[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        ncu[dev] = n / 8 * 8;
+    }
+    const long grid = nblk < ncu[dev] ? nblk : ncu[dev];
     const int epi = (bias ? 1 : 0) | (accumulate ? 2 : 0);
     const int var = g_variant < 0 ? 0 : g_variant;
-    typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long);
+    typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long, int,
+                          uint32_t*);
     kfn_t kfn = nullptr;
-#define GB_PICK(D_, PF_)                                                                        \
+    uint32_t* tr = (epi == 0) ? g_trace : nullptr;
+#define GB_PICK(D_, IC_)                                                                        \
     switch (epi) {                                                                              \
-        case 0: kfn = gb::gemm_bf16_kernel<D_, PF_, 0>; break;                                  \
-        case 1: kfn = gb::gemm_bf16_kernel<D_, PF_, 1>; break;                                  \
-        case 2: kfn = gb::gemm_bf16_kernel<D_, PF_, 2>; break;                                  \
-        default: kfn = gb::gemm_bf16_kernel<D_, PF_, 3>; break;                                 \
+        case 0: kfn = tr ? gb::gemm_bf16_kernel<D_, IC_, 0, true> : gb::gemm_bf16_kernel<D_, IC_, 0, false>; break; \
+        case 1: kfn = gb::gemm_bf16_kernel<D_, IC_, 1, false>; break;                           \
+        case 2: kfn = gb::gemm_bf16_kernel<D_, IC_, 2, false>; break;                           \
+        default: kfn = gb::gemm_bf16_kernel<D_, IC_, 3, false>; break;                          \
     }
-    switch (var & 3) {
-        case 0: GB_PICK(5, true) break;
-        case 1: GB_PICK(6, true) break;
-        case 2: GB_PICK(5, false) break;
-        default: GB_PICK(6, false) break;
+    if (var & 1) {
+        GB_PICK(5, false)
+    } else {
+        GB_PICK(6, true)
     }
 #undef GB_PICK
-    hipLaunchKernelGGL(kfn, dim3((unsigned)nblk), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
-                       bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
+                       bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc, (int)nblk, tr);
     return (int)hipGetLastError();
 }
 

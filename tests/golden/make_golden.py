@@ -427,6 +427,358 @@ def ppo_rl_small():
     config.DiscriConfig.update(big)
 
 
+class _reference_dqn_side:
+    """Context in which /root/reference/dqn_policy/{IRL_dqn_train,AIRL,AIRL_model}.py import and run on the CPU,
+    unmodified.  What the files need and this image lacks exists only inside the `with` block:
+      * `miditoolkit` (absent; IRL_dqn_train.py:16-17 imports it and never uses it), `wandb` (absent; `log` / `save` /
+        `init` are calls whose results nothing reads) and `utils` (IRL_dqn_train.py:21 / AIRL.py:15 import three plot
+        helpers from a module the reference does not contain): empty placeholder modules with no-op callables;
+      * `.cuda()` (DQN.__init__, the buffers' sampling / get, RewardDiscri): there is no GPU here, so Tensor.cuda and
+        Module.cuda return the object itself -- the arithmetic that follows is the reference's own, on the CPU;
+      * fast_transformers -> oracle/ft_standin (as for every other fixture: the encoder BODY is the restatement),
+        TrajectoryTransformer* placeholders for AIRL_model.py:10."""
+
+    def __enter__(self):
+        import types
+        _transformers_placeholders()
+        self.config, self.model = _import_reference("dqn_policy")
+        self.saved_mods = {k: sys.modules.get(k) for k in ("wandb", "miditoolkit", "miditoolkit.midi",
+                                                            "miditoolkit.midi.containers", "utils", "AIRL", "AIRL_model",
+                                                            "IRL_dqn_train")}
+        wb = types.ModuleType("wandb")
+        wb.log = wb.save = wb.init = lambda *a, **k: None
+        mt, mm, mc = (types.ModuleType(n) for n in ("miditoolkit", "miditoolkit.midi", "miditoolkit.midi.containers"))
+        for n in ("Marker", "Instrument", "TempoChange", "Note"):
+            setattr(mc, n, type(n, (), {}))
+        mt.midi, mm.containers = mm, mc
+        ut = types.ModuleType("utils")
+        ut.bi_loss_plot = ut.tri_loss_plot = ut.score_plotting = lambda *a, **k: None
+        sys.modules.update({"wandb": wb, "miditoolkit": mt, "miditoolkit.midi": mm, "miditoolkit.midi.containers": mc,
+                            "utils": ut})
+        for m in ("AIRL", "AIRL_model", "IRL_dqn_train"):
+            sys.modules.pop(m, None)
+        self.cuda = (torch.Tensor.cuda, torch.nn.Module.cuda)
+        torch.Tensor.cuda = lambda self_, *a, **k: self_
+        torch.nn.Module.cuda = lambda self_, *a, **k: self_
+        self.path = os.path.join(REF, "dqn_policy")
+        sys.path.insert(0, self.path)
+        self.am = importlib.import_module("AIRL_model")
+        self.airl = importlib.import_module("AIRL")
+        self.am.D_MODEL, self.am.N_LAYER, self.am.N_HEAD = 128, 2, 2
+        self.config.AgentConfig.update({"D_MODEL": 128, "N_LAYER": 2, "N_HEAD": 2})
+        return self
+
+    def train_module(self):
+        return importlib.import_module("IRL_dqn_train")
+
+    def __exit__(self, *exc):
+        torch.Tensor.cuda, torch.nn.Module.cuda = self.cuda
+        sys.path.remove(self.path)
+        for k, v in self.saved_mods.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+        self.config.AgentConfig.update({"D_MODEL": 512, "N_LAYER": 12, "N_HEAD": 8})
+        return False
+
+
+def _no_dropout(net):
+    """The reference scores and trains with dropout live (`all_forward` forces train(), AIRL.py:63); a record needs it
+    off: every nn.Dropout gets p = 0 and HF's Longformer self-attention its `dropout` probability 0.  BatchNorm stays as
+    the reference has it (train mode: batch statistics)."""
+    for m in net.modules():
+        if isinstance(m, torch.nn.Dropout):
+            m.p = 0.0
+        if isinstance(getattr(m, "dropout", None), float):
+            m.dropout = 0.0
+    return net
+
+
+def dqn_rl_small():
+    """The reference's own DQN-side classes (dqn_policy/IRL_dqn_train.py:78-345, dqn_policy/AIRL.py:33-91,121-236), small
+    nets (128 / 2 / 2), name-keyed fills, eval() (dropout off) so that the record is deterministic:
+      choose.*   DQN.choose_action on a fixed 50-token state (rows are positions [0, 49, 48, ...]: `-0 == 0`);
+      update.*   ONE DQN.update on a fixed batch of 30: MSE / CE / total loss, gradient slices of eval_net, a weight slice
+                 after the Adam step, the target sync; then 51 more updates: learning rate after every update
+                 (MultiStepLR [20, 40] stepped per update) and the second target sync at update 51;
+      ring.*     AgentMemory / ExpertMemory with BUFFER_SIZE 8: 11 stores (ring overwrite), get(), seeded sampling;
+      reward.*   RewardDiscri.update_disc(train=False) -> calculate_reward x 2 from a saved ./ckpt/disc_IRL.pt, 11 windows
+                 in batches of 4 (the 3-window tail keeps the initial 1.0), dropout p = 0, BatchNorm batch statistics."""
+    import contextlib
+    import io
+    import shutil
+    import tempfile
+    n_class = [56, 135, 18, 87, 18, 25]
+    out = {"n_class": np.array(n_class)}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    with _reference_dqn_side() as ref:
+        os.chdir(tmp)
+        try:
+            os.makedirs("ckpt")
+            os.makedirs("exp")
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                T = ref.train_module()
+                T.num = 0                                        # the module-level loop variable update() prints
+                T.first_loss, T.sec_loss, T.global_loss = [], [], []
+                agent = T.DQN(n_class, Pretrain=False)
+            fill_params(agent.eval_net, seed=61).eval()
+            fill_params(agent.target_net, seed=99).eval()        # different on purpose: update() must sync it
+            gen = torch.Generator().manual_seed(1357)
+            # ---- choose_action, :240-264 ----
+            x = _tokens(gen, (1, 50), n_class)
+            with torch.no_grad():
+                action = agent.choose_action(x, x)
+            out.update({"choose.x": x.numpy(), "choose.action": action.numpy()})
+            # ---- update, :267-345 ----
+            B = T.batch_size
+            st, ns, ex = _tokens(gen, (B, 50), n_class), _tokens(gen, (B, 50), n_class), _tokens(gen, (B, 50), n_class)
+            ac = _tokens(gen, (B, T.N_ACTIONS), n_class)
+            rw = torch.rand(B, 1, generator=gen)
+            dn = torch.randint(0, 2, (B, 1), generator=gen)
+            mask = (torch.rand(B, 50, generator=gen) > 0.2).float()
+            agent_tr = {"state": st, "action": ac, "reward": rw, "nextstate": ns, "done": dn}
+            expert_tr = {"state": st, "action": ac, "reward": rw, "nextstate": ex, "done": dn}
+            before = {k: v.clone() for k, v in agent.eval_net.state_dict().items()}
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                agent.update(agent_tr, expert_tr, mask, False, 0)
+            out.update({"update.state": st.numpy(), "update.nextstate": ns.numpy(), "update.expert_next": ex.numpy(),
+                        "update.action": ac.numpy(), "update.reward": rw.numpy(), "update.done": dn.numpy(),
+                        "update.mask": mask.numpy(),
+                        "update.losses": np.array([agent.mse_val, agent.ce_val, agent.total_val], dtype=np.float64),
+                        "update.target_synced": np.array(all(torch.equal(v, before[k]) for k, v in
+                                                             agent.target_net.state_dict().items()))})
+            ps = dict(agent.eval_net.named_parameters())
+            pick = ["in_linear.weight", "word_emb_pitch.lut.weight", "proj_chord.weight", "proj_tempo.bias",
+                    "transformer_encoder.layers.0.attention.query_projection.weight",
+                    "transformer_encoder.layers.0.attention.out_projection.bias",
+                    "transformer_encoder.layers.1.linear1.weight", "transformer_encoder.layers.1.linear2.weight",
+                    "transformer_encoder.layers.1.norm2.weight", "transformer_encoder.norm.bias"]
+            for k in pick:
+                g = ps[k].grad
+                out["update.grad." + k] = (g[:8] if g.numel() > 4096 else g).numpy()
+                w_ = ps[k].detach()
+                out["update.after." + k] = (w_[:8] if w_.numel() > 4096 else w_).numpy().copy()
+            names = sorted(k for k in ps if ps[k].grad is not None)
+            out["update.gradnames"] = np.array(names)
+            out["update.gradnorm"] = np.array([ps[k].grad.double().norm().item() for k in names])
+            lrs = [float(agent.optim.param_groups[0]["lr"])]
+            synced51 = None
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                for i in range(2, 53):                          # updates 2 .. 52
+                    if i == 51:
+                        pre = {k: v.clone() for k, v in agent.eval_net.state_dict().items()}
+                    agent.update(agent_tr, expert_tr, mask, False, 0)
+                    lrs.append(float(agent.optim.param_groups[0]["lr"]))
+                    if i == 50:                                  # target_count 49 -> no sync at update 50
+                        tgt50 = {k: v.clone() for k, v in agent.target_net.state_dict().items()}
+                    if i == 51:                                  # target_count 50 -> sync BEFORE the step of update 51
+                        synced51 = all(torch.equal(v, pre[k]) for k, v in agent.target_net.state_dict().items())
+            out["update.lr_after"] = np.array(lrs)               # lr_after[k] = learning rate after k + 1 updates
+            out["update.synced_at_51"] = np.array(bool(synced51))
+            out["update.target_unchanged_2_to_50"] = np.array(all(torch.equal(v, before[k]) for k, v in tgt50.items()))
+            out["update.counters"] = np.array([agent.target_count, agent.cnt_update])
+            # ---- ring overwrite + seeded sampling with a buffer of 8 slots and 11 stores, :78-204 ----
+            T.BUFFER_SIZE = 8
+            ab, eb = T.AgentMemory(), T.ExpertMemory()
+            g2 = torch.Generator().manual_seed(2468)
+            stored = {k: [] for k in ("state", "action", "reward", "next", "done", "mstate", "mnext")}
+            for i in range(11):
+                s_, n_ = _tokens(g2, (50,), n_class), _tokens(g2, (50,), n_class)
+                a_ = _tokens(g2, (T.N_ACTIONS,), n_class)
+                r_ = torch.rand((), generator=g2)
+                d_ = torch.tensor(i % 2).long()
+                ms, mn = (torch.rand(50, generator=g2) > 0.3).float(), (torch.rand(50, generator=g2) > 0.3).float()
+                ab.store_transition(s_, a_, r_, n_, d_)
+                eb.store_transition(s_, a_, r_, n_, d_, ms, mn)
+                for k, v in zip(stored, (s_, a_, r_, n_, d_, ms, mn)):
+                    stored[k].append(v.numpy())
+            for k, v in stored.items():
+                out["ring.in." + k] = np.stack(v)
+            for i, t in enumerate(ab.get()):
+                out["ring.agent_get.%d" % i] = t.numpy()
+            for i, t in enumerate(eb.get()):
+                out["ring.expert_get.%d" % i] = t.numpy()
+            out["ring.counter"] = np.array([ab.memory_counter, eb.memory_counter])
+            np.random.seed(4242)
+            for i, t in enumerate(ab.sampling(5)):
+                out["ring.agent_sample.%d" % i] = t.numpy()
+            for i, t in enumerate(eb.sampling(5)):
+                out["ring.expert_sample.%d" % i] = t.numpy()
+            # ---- RewardDiscri.update_disc(train=False) -> calculate_reward, AIRL.py:69-91,121-236 ----
+            with contextlib.redirect_stdout(io.StringIO()):
+                rd = ref.airl.RewardDiscri(n_class, Pretrain=False)
+            fill_params(rd.disc_model, seed=41)
+            with torch.no_grad():
+                rd.disc_model.score_classifier[1].running_mean.copy_(torch.linspace(-0.2, 0.2, 128))
+                rd.disc_model.score_classifier[1].running_var.copy_(torch.linspace(0.5, 1.5, 128))
+            _no_dropout(rd.disc_model)
+            torch.save({"epoch": 0, "model_state_dict": rd.disc_model.state_dict()}, rd.IRL_ckpt_path)
+            rd.batch_size = 4
+            g3 = torch.Generator().manual_seed(8642)
+            n_win = 11
+            a_states, a_next = _tokens(g3, (n_win, 50), n_class), _tokens(g3, (n_win, 50), n_class)
+            e_states, e_next = _tokens(g3, (n_win, 50), n_class), _tokens(g3, (n_win, 50), n_class)
+            dones = torch.zeros(n_win, 1).long()
+            m_states = torch.ones(n_win, 50)
+            m_states[2, 45:] = 0
+            m_states[6, 30:] = 0
+            m_next = torch.ones(n_win, 50)
+            agent_ep = (a_states, None, None, a_next, dones)
+            expert_ep = (e_states, None, None, e_next, dones, m_states, m_next)
+            with contextlib.redirect_stdout(io.StringIO()), contextlib.redirect_stderr(io.StringIO()):
+                traj, answer = rd.update_disc(agent_ep, expert_ep, train=False)
+            out.update({"reward.agent_states": a_states.numpy(), "reward.expert_states": e_states.numpy(),
+                        "reward.mask_states": m_states.numpy(), "reward.batch_size": np.array(4),
+                        "reward.traj": traj.numpy(), "reward.answer": answer.numpy()})
+            assert float(traj[8:].min()) == 1.0 and float(traj[:8].max()) < 1.0     # the tail keeps the initial 1.0
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+    np.savez_compressed(os.path.join(HERE, "dqn_rl_small.npz"), **out)
+
+
+def dqn_loop_small():
+    """The reference's own rollout loop -- the `__main__` block of dqn_policy/IRL_dqn_train.py:386-497 -- run on the CPU.
+    The file is parsed, five module constants are replaced IN MEMORY (NUM_SONGS 2, BUFFER_SIZE 60, the three absolute
+    paths -> a scratch directory holding a synthetic train_data_linear.npz / dictionary.pkl of the documented schema and a
+    `trainloss_13.pt`-style checkpoint of a small filled net) and one call is inserted behind `Rewarder = RewardDiscri(...)`
+    that puts both agent nets in eval(), switches the discriminator's dropout off and sets its scoring batch to 16
+    (so that 60 buffered windows give 3 scored batches and a 12-window tail); everything else executes as written:
+    two songs x 50 environment steps, and from the 61st step on (memory_counter > BUFFER_SIZE) re-scoring of both
+    buffers, the overwrite of every stored reward, the two `sampling` calls and `Agent.update`.
+    Recorded: every action, the rewards of every update_disc call, what every update was given and the three losses it
+    printed (6 decimals), gene_reward, and both buffers at the end."""
+    import ast
+    import contextlib
+    import io
+    import pickle
+    import re
+    import shutil
+    import tempfile
+    disk = [56, 135, 18, 3, 87, 18, 25]
+    n_class = [56, 135, 18, 87, 18, 25]
+    keys = ["tempo", "chord", "bar-beat", "type", "pitch", "duration", "velocity"]
+    songs, L, BUF = 2, 200, 60
+    gen = torch.Generator().manual_seed(31337)
+    x = torch.stack([torch.randint(0, n, (songs, L), generator=gen) for n in disk], -1).numpy()
+    y = torch.stack([torch.randint(0, n, (songs, L), generator=gen) for n in disk], -1).numpy()
+    mask = (torch.rand(songs, L, generator=gen) > 0.25).float().numpy()
+    out = {"x": x.astype(np.int16), "y": y.astype(np.int16), "mask": mask, "n_class": np.array(n_class),
+           "buffer_size": np.array(BUF), "score_batch": np.array(16), "np_seed": np.array(777)}
+    cwd = os.getcwd()
+    tmp = tempfile.mkdtemp()
+    rec = {"actions": [], "rewards": [], "upd": []}
+    with _reference_dqn_side() as ref:
+        os.chdir(tmp)
+        try:
+            os.makedirs("ckpt")
+            os.makedirs("exp")
+            np.savez(os.path.join(tmp, "train_data_linear.npz"), x=x, y=y, mask=mask)
+            e2w = {k: {"%s_%d" % (k, i): i for i in range(n)} for k, n in zip(keys, disk)}
+            w2e = {k: {i: e for e, i in v.items()} for k, v in e2w.items()}
+            with open(os.path.join(tmp, "dictionary.pkl"), "wb") as f:
+                pickle.dump((e2w, w2e), f)
+            with contextlib.redirect_stdout(io.StringIO()):
+                pre = fill_params(ref.model.LinearTransformer(n_class), seed=61)
+                disc = fill_params(ref.am.LongFormer(n_class), seed=41)
+            torch.save({"epoch": 0, "model_state_dict": pre.state_dict()}, os.path.join(tmp, "pretrain.pt"))
+            with torch.no_grad():
+                disc.score_classifier[1].running_mean.copy_(torch.linspace(-0.2, 0.2, 128))
+                disc.score_classifier[1].running_var.copy_(torch.linspace(0.5, 1.5, 128))
+            torch.save({"epoch": 0, "model_state_dict": disc.state_dict()}, "./ckpt/disc_IRL.pt")
+
+            def hook(Agent, Rewarder):
+                Agent.eval_net.eval()
+                Agent.target_net.eval()
+                _no_dropout(Rewarder.disc_model)
+                Rewarder.batch_size = 16
+                choose, update, upd_disc = Agent.choose_action, Agent.update, Rewarder.update_disc
+
+                def choose_rec(x_, target):
+                    a = choose(x_, target)
+                    rec["actions"].append(a.numpy().copy())
+                    return a
+
+                def update_rec(agent_transition, expert_transition, mask_next_states, update_flag, epoch):
+                    rec["upd"].append({"state": agent_transition["state"].numpy().copy(),
+                                       "action": agent_transition["action"].numpy().copy(),
+                                       "reward": agent_transition["reward"].numpy().copy(),
+                                       "nextstate": agent_transition["nextstate"].numpy().copy(),
+                                       "done": agent_transition["done"].numpy().copy(),
+                                       "e_nextstate": expert_transition["nextstate"].numpy().copy(),
+                                       "e_done": expert_transition["done"].numpy().copy(),
+                                       "mask": mask_next_states.numpy().copy(), "flag": bool(update_flag), "epoch": epoch,
+                                       "lr": float(Agent.optim.param_groups[0]["lr"])})
+                    return update(agent_transition, expert_transition, mask_next_states, update_flag, epoch)
+
+                def upd_disc_rec(agent_traj, expert_traj, train=True):
+                    r = upd_disc(agent_traj, expert_traj, train=train)
+                    rec["rewards"].append((r[0].numpy().copy(), r[1].numpy().copy(), bool(train)))
+                    return r
+
+                Agent.choose_action, Agent.update, Rewarder.update_disc = choose_rec, update_rec, upd_disc_rec
+
+            src = open(os.path.join(REF, "dqn_policy", "IRL_dqn_train.py")).read()
+            tree = ast.parse(src)
+            consts = {"NUM_SONGS": songs, "BUFFER_SIZE": BUF, "path_train_data": os.path.join(tmp, "train_data_linear.npz"),
+                      "path_dictionary": os.path.join(tmp, "dictionary.pkl"),
+                      "Pretrain_ckpt": os.path.join(tmp, "pretrain.pt")}
+            seen = set()
+            for node in tree.body:
+                if isinstance(node, ast.Assign) and len(node.targets) == 1 and isinstance(node.targets[0], ast.Name) \
+                        and node.targets[0].id in consts:
+                    node.value = ast.Constant(consts[node.targets[0].id])
+                    seen.add(node.targets[0].id)
+            assert seen == set(consts), seen
+            main_if = [n for n in tree.body if isinstance(n, ast.If)][-1]
+            at = [i for i, n in enumerate(main_if.body) if isinstance(n, ast.Assign) and isinstance(n.targets[0], ast.Name)
+                  and n.targets[0].id == "Rewarder"]
+            assert len(at) == 1
+            call = ast.Expr(ast.Call(ast.Name("_golden_hook", ast.Load()),
+                                     [ast.Name("Agent", ast.Load()), ast.Name("Rewarder", ast.Load())], []))
+            main_if.body.insert(at[0] + 1, call)
+            ast.fix_missing_locations(tree)
+            code = compile(tree, "<reference dqn_policy/IRL_dqn_train.py, constants patched in memory>", "exec")
+            ns = {"__name__": "__main__", "_golden_hook": hook}
+            np.random.seed(777)
+            log = io.StringIO()
+            with contextlib.redirect_stdout(log), contextlib.redirect_stderr(io.StringIO()):
+                exec(code, ns)
+        finally:
+            os.chdir(cwd)
+            shutil.rmtree(tmp, ignore_errors=True)
+    losses = [[float(v) for v in m] for m in
+              re.findall(r"MSE_Loss: ([-\d.naninf]+)\| CE_Loss: ([-\d.naninf]+)\| TD_Loss: ([-\d.naninf]+)", log.getvalue())]
+    n_upd = len(rec["upd"])
+    assert len(rec["actions"]) == songs * 50 and n_upd == songs * 50 - BUF and len(losses) == n_upd == len(rec["rewards"])
+    out["actions"] = np.stack(rec["actions"]).astype(np.int16)
+    out["traj_reward"] = np.stack([r[0] for r in rec["rewards"]])[:, :, 0]
+    out["answer_reward"] = np.stack([r[1] for r in rec["rewards"]])[:, :, 0]
+    out["update.losses"] = np.array(losses, dtype=np.float64)
+    out["update.lr_before"] = np.array([u["lr"] for u in rec["upd"]])
+    out["update.epoch"] = np.array([u["epoch"] for u in rec["upd"]])
+    for k in ("reward", "done", "e_done"):
+        out["update." + k] = np.stack([u[k] for u in rec["upd"]])
+    for k in ("state", "action", "nextstate", "e_nextstate", "mask"):
+        out["update3." + k] = np.stack([u[k] for u in rec["upd"][:3]]).astype(np.int16 if k != "mask" else np.float32)
+        out["update.sum." + k] = np.array([u[k].astype(np.float64).sum() for u in rec["upd"]])
+    ab, eb = ns["AgentBuffer"], ns["ExpertBuffer"]
+    out["gene_reward"] = np.array(ns["gene_reward"], dtype=np.float64)
+    out["final.agent_states"] = ab.states_agent.astype(np.int16)
+    out["final.agent_actions"] = ab.actions_agent.astype(np.int16)
+    out["final.agent_rewards"] = ab.rewards_agent.astype(np.float32)
+    out["final.agent_next"] = ab.next_states_agent.astype(np.int16)
+    out["final.expert_states"] = eb.states_exp.astype(np.int16)
+    out["final.expert_next"] = eb.next_states_exp.astype(np.int16)
+    out["final.expert_rewards"] = eb.rewards_exp.astype(np.float32)
+    out["final.mask_state"] = eb.mask_state.numpy()
+    out["final.mask_next_state"] = eb.mask_next_state.numpy()
+    out["final.counters"] = np.array([ab.memory_counter, eb.memory_counter])
+    np.savez_compressed(os.path.join(HERE, "dqn_loop_small.npz"), **out)
+
+
 def ppo_reward_grads_small():
     """Gradients THROUGH the PPO reward model (ppo_policy/model.py:459-495 `LongFormer.token_forward`, the function
     `my_pretrain.py --reward_pretrain` would train): d(sum of scores * w) / d(every parameter), reference's own class
@@ -524,6 +876,8 @@ if __name__ == "__main__":
     airl_grads_small()
     dqn_generation_small()
     ppo_rl_small()
+    dqn_rl_small()
+    dqn_loop_small()
     ppo_reward_grads_small()
     ppo_dataset_files()
     for f in sorted(os.listdir(HERE)):

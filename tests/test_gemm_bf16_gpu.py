@@ -19,7 +19,7 @@ BF16_TOL = 2.0 ** -7
 def _all_rows(monkeypatch):
     monkeypatch.setattr(ops, "GEMM_BF16_MIN_ROWS", 0)
     yield
-    _lib.load().cwlt_gemm_bf16_tune(-1)
+    _lib.load().cwlt_gemm_bf16_tune(-1, None)
 
 
 def _operands(M, N, K, seed, cuda, lda=None, ldw=None):
@@ -57,14 +57,14 @@ def test_gemm_bf16_matches_the_f64_product(cuda, M, N, K):
     _check(acc2, prod + c0.double() + bias.double())
 
 
-@pytest.mark.parametrize("variant", [0, 1, 2, 3])
+@pytest.mark.parametrize("variant", [0, 1])
 @pytest.mark.parametrize("K", [128, 192, 256, 320, 2048])
 def test_every_schedule_variant_and_short_reductions(cuda, variant, K):
     """K = 128 is two K-tiles (the peeled tail alone), 192 / 320 an odd count: the slot parity and the counted waits of the
-    last two K-tiles are exercised at every length; all four DMA-depth / pre-read variants must agree with the f64 product."""
+    last two K-tiles are exercised at every length; both DMA schedules must agree with the f64 product."""
     M, N = 777, 512
     a, w, bias, _ = _operands(M, N, K, 100 + K, cuda)
-    _lib.load().cwlt_gemm_bf16_tune(variant)
+    _lib.load().cwlt_gemm_bf16_tune(variant, None)
     out = ops.gemm_bf16(a.to(cuda), w.to(cuda), bias.to(cuda))
     _check(out, a.double() @ w.double().t() + bias.double())
 

@@ -1,7 +1,8 @@
 """Per-shape table of the projection GEMMs: cwlt_gemm_bf16 (csrc/gemm_bf16.hip) against hipBLASLt (torch.mm / addmm /
 addmm_) on the same box, same random operands, interleaved rounds in one process (GPU box only).
 
-usage: python tools/bench_gemm.py [M] [--variants 0,1,2,3] [--rounds 5]
+usage: python tools/bench_gemm.py [M] [--variants 0,1] [--rounds 5]
+       python tools/bench_gemm.py [M] --trace N K [--variants 0,1]     in-kernel s_memtime stamps of one tile (diagnostic build)
 Prints, per shape of the encoder layer at M token rows: correctness against an f64 product of the same bf16 operands,
 then median / min microseconds and TFLOP/s of both.
 """
@@ -46,6 +47,40 @@ def time_rounds(fns, rounds, n=10, warm=2):
     return out
 
 
+def trace(M, N, K, variants):
+    """Workgroup 0's second tile, stamped with s_memtime (shader cycles) by the diagnostic build: tile start, operands
+    landed, then every barrier of the main loop (start of each compute segment, start of each load segment), main loop
+    done, next tile's prologue issued, stores issued.  Printed per wave group (wave 0: leading half, wave 4: the half
+    that runs one barrier behind)."""
+    import numpy as np
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    nK = K // 64
+    for v in variants:
+        buf = torch.zeros(8 * 1024, dtype=torch.int32, device=dev)
+        lib.cwlt_gemm_bf16_tune(v, _lib.dev(buf))
+        for _ in range(3):
+            ops.gemm_bf16(a, w)
+        torch.cuda.synchronize()
+        st = buf.cpu().numpy().astype(np.int64).reshape(8, 1024) & 0xffffffff
+        lib.cwlt_gemm_bf16_tune(-1, None)
+        n = 2 + 8 * nK + 3
+        print("variant %d  N=%d K=%d (%d K-tiles): cycles (s_memtime)" % (v, N, K, nK))
+        for wv in (0, 4):
+            s_ = st[wv, :n]
+            d = np.diff(s_) % (1 << 32)
+            loop = d[1:1 + 8 * nK].reshape(nK, 8)
+            # stamp order inside a phase: [start of C] ... [end of C = start of next L]; d[1] is the first load segment
+            load_seg, comp_seg = loop[:, 0::2], loop[:, 1::2]
+            print("  wave %d: operands landed after %d | main loop %d = %.0f per K-tile | load segments (incl. barrier wait) "
+                  "median %s | compute segments median %s | prologue issue %d | epilogue %d | tile %d"
+                  % (wv, d[0], loop.sum(), loop.sum() / nK, np.median(load_seg, 0).astype(int).tolist(),
+                     np.median(comp_seg, 0).astype(int).tolist(), d[2 + 8 * nK], d[3 + 8 * nK], s_[-1] - s_[0]))
+            print("          first K-tile %s   last K-tile %s" % (loop[0].tolist(), loop[-1].tolist()))
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     M = int(args[0]) if args else 524288
@@ -56,11 +91,14 @@ def main():
             variants = [int(v) for v in sys.argv[i + 1].split(",")]
         if a == "--rounds":
             rounds = int(sys.argv[i + 1])
+    if "--trace" in sys.argv:
+        i = sys.argv.index("--trace")
+        return trace(M, int(sys.argv[i + 1]), int(sys.argv[i + 2]), variants)
     gemm_tuning.enable()
     lib = _lib.load()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    print("M = %d rows; variants: bit 0 = DMA 6 half-tiles ahead (default 5), bit 1 = no pre-read of the next K-tile" % M)
+    print("M = %d rows; variant 0: DMA pieces between the MFMAs, 6 half-tiles ahead; 1: at the end of the load segment, 5 ahead" % M)
     for name, N, K, has_bias, acc, form in SHAPES:
         a = torch.randn(M, K, device=dev).bfloat16()
         w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
@@ -75,7 +113,7 @@ def main():
         if acc:
             ref = ref + c0[sl].double()
         for v in variants:
-            lib.cwlt_gemm_bf16_tune(v)
+            lib.cwlt_gemm_bf16_tune(v, None)
             out = c0.clone() if acc else None
             out = ops.gemm_bf16(a, w, bias, out=out, accumulate=acc)
             err = (out[sl].double() - ref).abs().max().item() / ref.abs().max().item()
@@ -97,7 +135,7 @@ def main():
         fns = [lt]
         for v in variants:
             def run(v=v):
-                lib.cwlt_gemm_bf16_tune(v)
+                lib.cwlt_gemm_bf16_tune(v, None)
                 ops.gemm_bf16(a, w, bias, out=cacc2 if acc else cw, accumulate=acc)
             fns.append(run)
         ts = time_rounds(fns, rounds)
@@ -112,7 +150,7 @@ def main():
             line += " | v%d %s" % (v, fmt(ts[1 + i]))
         print(line, flush=True)
         del a, w, c0, cw, cacc, cacc2
-    lib.cwlt_gemm_bf16_tune(-1)
+    lib.cwlt_gemm_bf16_tune(-1, None)
 
 
 if __name__ == "__main__":
