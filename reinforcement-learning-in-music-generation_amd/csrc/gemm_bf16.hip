@@ -83,11 +83,13 @@ typedef __attribute__((address_space(3))) void lds_void;
 #define GB_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
 // EPI bits: 1 = bias, 2 = accumulate onto C.  TRACE: s_memtime stamps of one tile's segments (diagnostic build).
-template <int D, bool IC, int EPI, bool TRACE>
+// ABL (timing experiments only, results are wrong): 1 = no DMA pieces inside the main loop, 2 = no fragment reads inside
+// it, 4 = no barriers inside it.
+template <int D, bool IC, int EPI, bool TRACE, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                             const float* __restrict__ bias, bf16_t* C, long M, int N,
                                                             int K, long lda, long ldw, long ldc, int nblk,
-                                                            uint32_t* __restrict__ trace) {
+                                                            uint32_t* __restrict__ trace, int stagger) {
     static_assert((D == 5 && !IC) || (D == 6 && IC), "wait counts below are written for these two schedules");
     __shared__ __attribute__((aligned(1024))) char lds[RING + EXTRA];
     float* lds_bias = reinterpret_cast<float*>(lds + RING);
@@ -164,16 +166,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         if (lane == 0) lds_trace[w * 1024 + (tq & 1023)] = now_;                           \
         ++tq;                                                                              \
     }
-#define GB_READ_A(dst, mh, k)                                                              \
+#define GB_READ_A_(dst, mh, k)                                                             \
     _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                    \
         dst[mb_][k] = GB_FRAG(bufo + ((mh) ? 3 : 0) * HALF + a_off[k] + mb_ * 2048);
+#define GB_READ_A(dst, mh, k) if (!(ABL & 2)) { GB_READ_A_(dst, mh, k) }
 #define GB_READ_AN(bufn)                                                                   \
     _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                    \
         AN[mb_] = GB_FRAG((bufn) + a_off[0] + mb_ * 2048);
-#define GB_READ_W(dst, nh)                                                                 \
+#define GB_READ_W_(dst, nh)                                                                \
     _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                       \
         _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                   \
             dst[b_][k_] = GB_FRAG(bufo + (1 + (nh)) * HALF + w_off[k_] + b_ * 512);
+#define GB_READ_W(dst, nh) if (!(ABL & 2)) { GB_READ_W_(dst, nh) }
 #define GB_MFMA4(WF, mh, nh, b_, k_)                                                       \
     _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                    \
         acc[2 * (nh) + (b_)][4 * (mh) + mb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
@@ -183,21 +187,21 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
     // IC = true: with the phase's two pieces behind the 4th and the 12th -- and the closing barrier
 #define GB_PHASE(WF, mh, nh, issue, j, tp, vm)                                             \
     __builtin_amdgcn_sched_barrier(0);                                                     \
-    if (!IC && (issue)) GB_ISSUE(j, tp)                                                    \
+    if (!IC && (issue) && !(ABL & 1)) GB_ISSUE(j, tp)                                      \
     GB_WAIT(vm);                                                                           \
-    __builtin_amdgcn_s_barrier();                                                          \
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     GB_STAMP()                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                         \
     GB_MFMA4(WF, mh, nh, 0, 0)                                                             \
-    if (IC && (issue)) {                                                                   \
+    if (IC && (issue) && !(ABL & 1)) {                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         GB_ISSUE1(j, tp, 0)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }                                                                                      \
     GB_MFMA4(WF, mh, nh, 1, 0)                                                             \
     GB_MFMA4(WF, mh, nh, 0, 1)                                                             \
-    if (IC && (issue)) {                                                                   \
+    if (IC && (issue) && !(ABL & 1)) {                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         GB_ISSUE1(j, tp, 1)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                 \
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
     GB_MFMA4(WF, mh, nh, 1, 1)                                                             \
     __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                     \
-    __builtin_amdgcn_s_barrier();                                                          \
+    if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     GB_STAMP()
 
@@ -226,7 +230,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         GB_READ_A(AF, 1, 1)                                                                                \
         GB_PHASE(WF1, 1, 1, i3, (D + 2) & 3, (t) + ((D + 2) >> 2), v3)                                     \
         /* phase 4: (rows half 1, columns half 0); W half 0 is still in registers */                       \
-        if (!(last)) { GB_READ_AN(bufo ^ (4 * HALF)) }                                                     \
+        if (!(last) && !(ABL & 2)) { GB_READ_AN(bufo ^ (4 * HALF)) }                                       \
         GB_PHASE(WF0, 1, 0, i4, (D + 3) & 3, (t) + ((D + 3) >> 2), v4)                                     \
         bufo ^= 4 * HALF;                                                                                  \
     }
@@ -268,6 +272,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 #define GB_PROLOGUE()                                                                      \
     _Pragma("unroll") for (int g = 0; g < D; ++g) GB_ISSUE(g & 3, g >> 2)
 
+    // Every workgroup takes the same time per tile, so left alone the whole chip stores its 256 x 128 KiB of output and
+    // requests the next tiles' first operands in the same few microseconds and then leaves HBM idle for a main loop.
+    // Workgroups start `stagger` x 64 cycles apart in 16 groups (spread over a fraction of a tile period), after which
+    // the bursts of different CUs fall into each other's main loops.
+    if (stagger) {
+        for (int left = ((blockIdx.x >> 3) & 15) * stagger; left > 0; left -= 64) __builtin_amdgcn_s_sleep(64);
+    }
     int idx = blockIdx.x;
     while (idx < nblk) {           // padding tiles (row tiles are dealt in eights) hold no rows
         GB_TILE(idx, mc_, nc_)
@@ -304,6 +315,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         __builtin_amdgcn_sched_barrier(0);
         GB_STAMP()
         GB_READ_AN(0)
+        if (ABL & 2) {                                      // timing experiment: the fragments are read once per tile
+            GB_READ_A_(AF, 0, 0) GB_READ_A_(AF, 0, 1) GB_READ_W_(WF0, 0) GB_READ_W_(WF1, 1)
+        }
         if (wm) __builtin_amdgcn_s_barrier();               // waves 4-7 run one barrier behind waves 0-3
         __builtin_amdgcn_sched_barrier(0);
 
@@ -428,6 +442,8 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 #undef GB_MFMA4
 #undef GB_READ_W
 #undef GB_READ_A
+#undef GB_READ_W_
+#undef GB_READ_A_
 #undef GB_READ_AN
 #undef GB_ISSUE
 #undef GB_ISSUE1
@@ -441,13 +457,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 }  // namespace gb
 }  // namespace cwlt
 
-static int g_variant = -1;      // -1: default; bit 0: the other schedule
+static int g_variant = -1;      // -1: default; see cwlt_gemm_bf16_tune
 static uint32_t* g_trace = nullptr;
 
 extern "C" {
 
-/* Tuning switch for A/B measurements (tools/bench_gemm.py): bit 0 selects the other DMA schedule (pieces issued at the
- * end of the load segment, 5 half-tiles ahead, instead of between the MFMAs, 6 ahead); variant < 0 restores the default.
+/* Tuning switch for A/B measurements (tools/bench_gemm.py); variant < 0 restores the default.  Bit 0: the other DMA
+ * schedule (pieces issued between the MFMAs of the compute segment, 6 half-tiles ahead, instead of at the end of the load
+ * segment, 5 ahead).  Bits 1-3: start stagger of the workgroups, in eighths of a tile period (default 0).  Bits 4-6
+ * (bias-free, non-accumulating launches only): timing experiments with WRONG results -- 1 no DMA pieces, 2 no fragment
+ * reads, 4 no barriers inside the main loop.  Bits 8-15: at most that many x 8 workgroups (0: one per CU).
  * trace != NULL (8192 uint32 of device memory): the next bias-free, non-accumulating launches run the diagnostic build,
  * which leaves the s_memtime stamps of workgroup 0's second tile there (8 waves x 1024). */
 int cwlt_gemm_bf16_tune(int variant, void* trace) {
@@ -486,11 +505,22 @@ int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int
         if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
         ncu[dev] = n / 8 * 8;
     }
-    const long grid = nblk < ncu[dev] ? nblk : ncu[dev];
+    long grid = nblk < ncu[dev] ? nblk : ncu[dev];
     const int epi = (bias ? 1 : 0) | (accumulate ? 2 : 0);
     const int var = g_variant < 0 ? 0 : g_variant;
+    const int glim = ((var >> 8) & 255) * 8;
+    if (glim && glim < grid) grid = glim;
+    // start stagger: (var >> 1 & 7) / 8 of a tile period (~3 500 cycles per K-tile + ~14 000 per tile) over 16 groups,
+    // in units of 64 cycles
+    // Default: half a tile period for K <= 1024 (there a tile's 128 KiB of stores + the next tile's first operands are a
+    // third of its time, and with every workgroup at the same point the chip alternates between saturating HBM and
+    // leaving it idle: 336 -> 300 us at K = N = 512, R = 524 288), none above (a K = 2048 tile is 55 us of main loop:
+    // 905 us with or without, and the stagger costs its own length once per launch).
+    const int stag8 = g_variant < 0 ? (K <= 1024 ? 4 : 0) : ((var >> 1) & 7);
+    const int stagger = (int)(stag8 * ((K / gb::BK) * 3500L + 14000L) / (8 * 16 * 64));
+    const int abl = (var >> 4) & 7;
     typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long, int,
-                          uint32_t*);
+                          uint32_t*, int);
     kfn_t kfn = nullptr;
     uint32_t* tr = (epi == 0) ? g_trace : nullptr;
 #define GB_PICK(D_, IC_)                                                                        \
@@ -501,13 +531,24 @@ int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int
         default: kfn = gb::gemm_bf16_kernel<D_, IC_, 3, false>; break;                          \
     }
     if (var & 1) {
-        GB_PICK(5, false)
-    } else {
         GB_PICK(6, true)
+    } else {
+        GB_PICK(5, false)
     }
 #undef GB_PICK
+    if (epi == 0 && !tr && abl) {
+        switch (abl) {
+            case 1: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 1>; break;
+            case 2: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 2>; break;
+            case 3: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 3>; break;
+            case 4: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 4>; break;
+            case 5: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 5>; break;
+            case 6: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 6>; break;
+            default: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 7>; break;
+        }
+    }
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
-                       bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc, (int)nblk, tr);
+                       bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc, (int)nblk, tr, stagger);
     return (int)hipGetLastError();
 }
 

@@ -7,7 +7,10 @@ read like the reference's, and the modules keep the package's parameter names
 `norm`), so reference checkpoints load unchanged.
 
 Each encoder layer is ONE autograd node with an explicit forward/backward schedule:
-  GEMMs (the only MFMA work) go to hipBLASLt through torch.mm/addmm on the activations' dtype;
+  the dense projections (the only MFMA work) are libcwlt GEMMs in bf16 at training sizes -- cwlt_gemm_bf16 for the
+  plain forward / input-gradient products (ops.gemm_bf16), the FFN and residual-block forms with their epilogues
+  (ops.ffn1_gelu_dropout, ops.gemm_nt_mul, ops.linear_ln), cwlt_wgrad_bf16 for the weight gradients; f32 parity runs
+  and steps of a few thousand token rows go to hipBLASLt through torch.mm/addmm;
   everything between them is a libcwlt HIP kernel -- fused QKV projection feeding the causal
   linear attention scan in place, residual+dropout+LayerNorm, bias+GELU+dropout -- and the backward
   folds bias / gamma / beta gradients into the same passes.
@@ -63,7 +66,10 @@ class _EncoderLayerFn(torch.autograd.Function):
             bo_a, b2_a = bo.to(adt), b2.to(adt)
         g1f, be1f, g2f, be2f, b1f = (ops._f32(t) for t in (g1, be1, g2, be2, b1))
 
-        qkv = torch.addmm(bqkv, x2, wqkv.t())                              # (R, 3D)  MFMA
+        if ops.gemm_bf16_supported(x2, wqkv):
+            qkv = ops.gemm_bf16(x2, wqkv, torch.cat([ops._f32(bq), ops._f32(bk), ops._f32(bv)]))   # (R, 3D)  MFMA
+        else:
+            qkv = torch.addmm(bqkv, x2, wqkv.t())
         qkv5 = qkv.view(N, L, 3, H, D // H)
         # with a backward to follow, the bf16 scan also hands over its final state: the backward is then one sweep
         _, _, _, a, zinv, fin = ops.cla_fwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2],
@@ -75,7 +81,8 @@ class _EncoderLayerFn(torch.autograd.Function):
             # reaches HBM (ops.linear_ln; the bias enters in f32)
             s1, x1, mean1, rstd1 = ops.linear_ln(a2, wo_a, ops._f32(bo), x2, g1f, be1f, ops.LN_EPS, p, seeds[0])
         else:
-            o = torch.addmm(bo_a, a2, wo_a.t())                            # MFMA
+            o = (ops.gemm_bf16(a2, wo_a, ops._f32(bo)) if ops.gemm_bf16_supported(a2, wo_a)
+                 else torch.addmm(bo_a, a2, wo_a.t()))                     # MFMA
             s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
             del o
         # bf16, when a backward will follow: the activation pass also leaves gd = mask / (1 - p) * gelu'(h + b1) (in place
@@ -87,13 +94,15 @@ class _EncoderLayerFn(torch.autograd.Function):
         if fused_ffn and FUSED_FFN_FWD and ops.ffn1_fused_supported(x1, w1_a, b1f):
             g, h = ops.ffn1_gelu_dropout(x1, w1_a, b1f, p, seeds[1])      # h holds gd
         else:
-            h = torch.mm(x1, w1_a.t())                                     # (R, F)  MFMA, bias in next kernel
+            h = (ops.gemm_bf16(x1, w1_a) if ops.gemm_bf16_supported(x1, w1_a)
+                 else torch.mm(x1, w1_a.t()))                              # (R, F)  MFMA, bias in next kernel
             fused_ffn = fused_ffn and h.is_contiguous()
             g = ops.gelu_fwd(h, b1f, p, seeds[1], gd_inplace=fused_ffn)
         if ops.linear_ln_supported(g, w2_a, x1):
             s2, out, mean2, rstd2 = ops.linear_ln(g, w2_a, ops._f32(b2), x1, g2f, be2f, ops.LN_EPS, p, seeds[2])
         else:
-            y = torch.addmm(b2_a, g, w2_a.t())                             # MFMA
+            y = (ops.gemm_bf16(g, w2_a, ops._f32(b2)) if ops.gemm_bf16_supported(g, w2_a)
+                 else torch.addmm(b2_a, g, w2_a.t()))                      # MFMA
             s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
             del y
 
@@ -127,7 +136,13 @@ class _EncoderLayerFn(torch.autograd.Function):
         # ... at large R; below ~16k rows the three 2 MB transposes cost more than the GEMMs gain
         nt = os.environ.get("CWLT_DGRAD_NT", "1") != "0" and dy.dtype == torch.bfloat16 and R >= 16384
 
-        def dgrad(g_, w_):
+        # bf16 at training sizes: cwlt_gemm_bf16 on the transposed weight (both operands K-contiguous; a 0.5-2 MB copy),
+        # `out` = the residual gradient the product is added onto
+        def dgrad(g_, w_, out=None):
+            if ops.gemm_bf16_supported(g_, w_.t(), out, transposed_w=True):
+                return ops.gemm_bf16(g_, w_.t().contiguous(), out=out, accumulate=out is not None)
+            if out is not None:
+                return out.addmm_(g_, w_.t().contiguous().t() if nt else w_)
             return torch.mm(g_, w_.t().contiguous().t()) if nt else torch.mm(g_, w_)
 
         dw2 = wgrad(dy, g)                                                 # (D, F)
@@ -143,7 +158,7 @@ class _EncoderLayerFn(torch.autograd.Function):
             # linear1's input gradient lands ON the residual gradient (C = D = ds2, beta = 1): norm1's backward then
             # reads one gradient stream instead of two, and the extra read sits in a GEMM that has HBM time to spare.
             # dy may alias ds2 (p = 0); its last readers (dw2, dh) are already enqueued.
-            ds2.addmm_(dh, w1_a.t().contiguous().t() if nt else w1_a)       # (R, D)
+            dgrad(dh, w1_a, out=ds2)                                       # (R, D)
             dx1 = None
         else:
             dx1 = dgrad(dh, w1_a)                                          # (R, D)
@@ -157,8 +172,11 @@ class _EncoderLayerFn(torch.autograd.Function):
                                   want_colsum=True, final_state=ctx.fin)
         ctx.fin = None
         dqkv2 = dqkv.view(R, 3 * D)
-        dx = ds1.addmm_(dqkv2, wqkv)                                       # residual + projection gradient, in place
-                                                                           # (NN is the faster form for this shape)
+        if ops.gemm_bf16_supported(dqkv2, wqkv.t(), ds1, transposed_w=True):
+            dx = ops.gemm_bf16(dqkv2, wqkv.t().contiguous(), out=ds1, accumulate=True)
+        else:
+            dx = ds1.addmm_(dqkv2, wqkv)                                   # residual + projection gradient, in place
+                                                                           # (NN is hipBLASLt's faster form for this shape)
                                                                            # (out-of-place addmm first copies ds1: 268 MB)
         dwqkv = wgrad(dqkv2, x2)                                           # (3D, D)
         layer = ctx.layer

@@ -655,11 +655,14 @@ GEMM_BF16_MIN_ROWS = int(os.environ.get("CWLT_GEMM_BF16_MIN_ROWS", 32768))
 GEMM_BF16 = os.environ.get("CWLT_GEMM_BF16", "1") != "0"
 
 
-def gemm_bf16_supported(a, w, c=None):
+def gemm_bf16_supported(a, w, c=None, transposed_w=False):
+    """Whether `gemm_bf16(a, w, out=c)` can run.  transposed_w: `w` is a transposed VIEW of a stored weight that the
+    caller will make contiguous first (the input-gradient forms): only its shape is looked at."""
     return (GEMM_BF16 and a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and a.dim() == 2 and w.dim() == 2
-            and a.shape[1] == w.shape[1] and a.shape[1] % 64 == 0 and a.shape[1] >= 128 and w.shape[0] % 8 == 0
-            and a.shape[0] >= GEMM_BF16_MIN_ROWS
-            and all(t.stride(1) == 1 and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0 for t in (a, w))
+            and a.is_cuda and a.shape[1] == w.shape[1] and a.shape[1] % 64 == 0 and a.shape[1] >= 128
+            and w.shape[0] % 8 == 0 and w.shape[0] <= 8192 and a.shape[0] >= GEMM_BF16_MIN_ROWS
+            and a.stride(1) == 1 and a.stride(0) % 8 == 0 and a.data_ptr() % 16 == 0
+            and (transposed_w or (w.stride(1) == 1 and w.stride(0) % 8 == 0 and w.data_ptr() % 16 == 0))
             and (c is None or (c.dtype == torch.bfloat16 and c.shape == (a.shape[0], w.shape[0]) and c.stride(1) == 1
                                and c.stride(0) % 8 == 0 and c.data_ptr() % 16 == 0)))
 
@@ -808,13 +811,18 @@ class LinearWgradFn(torch.autograd.Function):
         w16, b16 = _cast_pair(w, b, x.dtype)
         ctx.save_for_backward(x)
         ctx.w16 = w16              # a persistent shadow buffer when w is a Parameter: not version-tracked on purpose
+        if gemm_bf16_supported(x, w16):
+            return gemm_bf16(x, w16, _f32(b))
         return torch.addmm(b16, x, w16.t())
 
     @staticmethod
     def backward(ctx, dy):
         (x,), w16 = ctx.saved_tensors, ctx.w16
         dy = dy.contiguous()
-        dx = torch.mm(dy, w16) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = (gemm_bf16(dy, w16.t().contiguous()) if gemm_bf16_supported(dy, w16.t(), transposed_w=True)
+                  else torch.mm(dy, w16))
         dw = wgrad(dy, x) if wgrad_supported(dy, x) else torch.mm(dy.t(), x).float()
         return dx, dw, colsum(dy)
 
@@ -838,6 +846,8 @@ def linear(x, w, b):
         return LinearWgradFn.apply(x, w, b)
     if not torch.is_grad_enabled():
         w16, b16 = _cast_pair(w, b, x.dtype)
+        if x.dim() == 2 and gemm_bf16_supported(x, w16):
+            return gemm_bf16(x, w16, _f32(b))
         return torch.nn.functional.linear(x, w16, b16)
     return torch.nn.functional.linear(x, w.to(x.dtype), b.to(x.dtype))
 

@@ -83,7 +83,10 @@ def test_one_update_and_the_schedule_match_the_reference(cuda, small_agent):
             v = ps[k].detach()
             v = (v[:8] if v.numel() > 4096 else v).cpu()
             solid = _t(FX["update.grad." + k]).abs() > 1e-5      # Adam's first step: lr g / (|g| + 1e-8)
-            assert (v - _t(FX[key]))[solid].abs().max().item() <= TOL, k
+            if solid.any():
+                assert (v - _t(FX[key]))[solid].abs().max().item() <= TOL, k
+            # everywhere: one step moves a weight by at most lr = 1e-2 (+ rounding)
+            assert (v - _t(FX[key])).abs().max().item() <= 2.1e-2, k
     # updates 2..52: MultiStepLR per update, no target sync until target_count reaches 50 (update 51)
     lrs = [float(agent.optim.param_groups[0]["lr"])]
     for i in range(2, 53):

@@ -136,3 +136,57 @@ def test_bench_rows(cuda):
             sc = max(1.0, ref.abs().max().item())
             assert (out[sl].double() - ref).abs().max().item() <= BF16_TOL * sc
         del a, w, out, c0
+
+
+def test_encoder_on_the_hand_written_projections_equals_the_library_path(cuda, monkeypatch):
+    """Training mode, dropout ON, bf16, d_model 512, 3 layers: same seeds -> same masks whether the plain projections of a
+    layer (QKV forward, linear2 forward, the three input gradients, the heads) run on cwlt_gemm_bf16 or on hipBLASLt;
+    losses and every parameter gradient agree to what a differing bf16 rounding of the products can do."""
+    import os
+    import sys
+    import numpy as np
+    HERE = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    from fill import fill_params
+    from rlmg_amd.dqn_policy import config, model
+    n_class = [56, 135, 18, 87, 18, 25]
+    B, T = 2, 256
+    g = torch.Generator().manual_seed(12)
+    x = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1).to(cuda)
+    y = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1).to(cuda)
+    mask = torch.ones(B, T, device=cuda)
+    monkeypatch.setattr(ops, "LINEAR_LN_MIN_ROWS", 1 << 40)    # the residual blocks as GEMM + LayerNorm kernel: their GEMMs
+    runs = {}                                                   # (out-projection, linear2) then go through this switch too
+    old = dict(config.AgentConfig)
+    config.AgentConfig.update({"D_MODEL": 512, "N_LAYER": 3, "N_HEAD": 8})
+    try:
+        for hand in (True, False):
+            monkeypatch.setattr(ops, "GEMM_BF16", hand)
+            net = fill_params(model.LinearTransformer(n_class), seed=57).to(cuda).train()
+            net.compute_dtype = torch.bfloat16
+            torch.manual_seed(77)                               # ops.next_seed() draws from torch's CPU generator
+            calls = []
+            real = ops.gemm_bf16
+            monkeypatch.setattr(ops, "gemm_bf16", lambda *a_, **k_: (calls.append(1), real(*a_, **k_))[1])
+            losses = net.train_step(x, y, mask)
+            (sum(losses) / 6).backward()
+            monkeypatch.setattr(ops, "gemm_bf16", real)
+            # per layer: QKV, out-projection, linear2 forward; linear1 / out-projection / QKV input gradients; + the heads
+            # forward and the heads' input gradient
+            # (+ in_linear's forward and input gradient where the front is not the one-pass embed kernel)
+            assert len(calls) in ((3 * 6 + 2, 3 * 6 + 4) if hand else (0,)), len(calls)
+            runs[hand] = ([l.item() for l in losses],
+                          {n_: p.grad.detach().double().cpu() for n_, p in net.named_parameters() if p.grad is not None})
+    finally:
+        config.AgentConfig.update(old)
+    la, lb = np.array(runs[True][0]), np.array(runs[False][0])
+    assert np.abs(la - lb).max() <= 2e-3 * np.abs(lb).max(), (la, lb)
+    ga, gb = runs[True][1], runs[False][1]
+    assert ga.keys() == gb.keys()
+    # two bf16 schedules of the same step (test_gemm_ln_gpu.py): 7.1 % of the tensor's own norm, with a floor of 2e-4 of
+    # the rms tensor norm for gradients that are rounding noise in both (key_projection.bias: norm 7e-6 beside 1e-2 .. 1
+    # for the rest; its two noise draws differ by ~10 % of that)
+    rms = float(np.sqrt(np.mean([gb[k].norm().item() ** 2 for k in gb])))
+    for k in gb:
+        d = (ga[k] - gb[k]).norm().item()
+        assert d <= 7.1e-2 * max(gb[k].norm().item(), 2e-4 * rms), (k, d, gb[k].norm().item(), rms)

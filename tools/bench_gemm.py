@@ -3,6 +3,7 @@ addmm_) on the same box, same random operands, interleaved rounds in one process
 
 usage: python tools/bench_gemm.py [M] [--variants 0,1] [--rounds 5]
        python tools/bench_gemm.py [M] --trace N K [--variants 0,1]     in-kernel s_memtime stamps of one tile (diagnostic build)
+       python tools/bench_gemm.py [M] --ablate N K                     main-loop ablations, start staggers, small grids
 Prints, per shape of the encoder layer at M token rows: correctness against an f64 product of the same bf16 operands,
 then median / min microseconds and TFLOP/s of both.
 """
@@ -81,6 +82,41 @@ def trace(M, N, K, variants):
             print("          first K-tile %s   last K-tile %s" % (loop[0].tolist(), loop[-1].tolist()))
 
 
+def ablate(M, N, K, rounds):
+    """Where the tile time goes (results of the ablated kernels are wrong by construction): main loop with parts switched
+    off, grids smaller than the chip (is the tile boundary bandwidth- or latency-bound?), start staggers."""
+    lib = _lib.load()
+    dev = torch.device("cuda:0")
+    a = torch.randn(M, K, device=dev).bfloat16()
+    w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
+    c = torch.empty(M, N, device=dev, dtype=torch.bfloat16)
+    names = {0: "everything", 1: "no DMA in the loop", 2: "no fragment reads", 3: "no DMA, no reads (MFMA + barriers)",
+             4: "no barriers", 5: "no DMA, no barriers", 6: "no reads, no barriers", 7: "MFMA only"}
+
+    def run(v):
+        def f():
+            lib.cwlt_gemm_bf16_tune(v, None)
+            ops.gemm_bf16(a, w, out=c)
+        return f
+    fl = 2.0 * M * N * K
+    print("N=%d K=%d M=%d: main-loop ablations (us, median of %d rounds)" % (N, K, M, rounds))
+    ts = time_rounds([run(ab << 4) for ab in range(8)], rounds)
+    for ab in range(8):
+        t = sorted(ts[ab])[len(ts[ab]) // 2]
+        print("  %-36s %8.1f us (%5.0f TF-equivalent)" % (names[ab], t * 1e3, fl / t / 1e9))
+    print("start stagger (eighths of a tile period over 16 groups of workgroups):")
+    ts = time_rounds([run(sg << 1) for sg in range(8)], rounds)
+    for sg in range(8):
+        t = sorted(ts[sg])[len(ts[sg]) // 2]
+        print("  stagger %d/8  %8.1f us (%5.0f TF)" % (sg, t * 1e3, fl / t / 1e9))
+    print("grid limited to g workgroups (time x g / 256 = time the whole chip would need at that per-CU rate):")
+    for g8 in (4, 8, 16, 32):
+        ts = time_rounds([run(g8 << 8)], max(2, rounds // 2), n=3)
+        t = sorted(ts[0])[len(ts[0]) // 2]
+        print("  %3d workgroups  %9.1f us  -> x g/256 = %8.1f us" % (g8 * 8, t * 1e3, t * 1e3 * g8 * 8 / 256))
+    lib.cwlt_gemm_bf16_tune(-1, None)
+
+
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     M = int(args[0]) if args else 524288
@@ -91,6 +127,9 @@ def main():
             variants = [int(v) for v in sys.argv[i + 1].split(",")]
         if a == "--rounds":
             rounds = int(sys.argv[i + 1])
+    if "--ablate" in sys.argv:
+        i = sys.argv.index("--ablate")
+        return ablate(M, int(sys.argv[i + 1]), int(sys.argv[i + 2]), rounds)
     if "--trace" in sys.argv:
         i = sys.argv.index("--trace")
         return trace(M, int(sys.argv[i + 1]), int(sys.argv[i + 2]), variants)
@@ -98,7 +137,7 @@ def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    print("M = %d rows; variant 0: DMA pieces between the MFMAs, 6 half-tiles ahead; 1: at the end of the load segment, 5 ahead" % M)
+    print("M = %d rows; variant bit 0: DMA pieces between the MFMAs (default: at the end of the load segment); bits 1-3: start stagger in eighths of a tile" % M)
     for name, N, K, has_bias, acc, form in SHAPES:
         a = torch.randn(M, K, device=dev).bfloat16()
         w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
