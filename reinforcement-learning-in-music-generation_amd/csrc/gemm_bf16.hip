@@ -84,13 +84,17 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // EPI bits: 1 = bias, 2 = accumulate onto C.  TRACE: s_memtime stamps of one tile's segments (diagnostic build).
 // ABL (timing experiments only, results are wrong): 1 = no DMA pieces inside the main loop, 2 = no fragment reads inside
-// it, 4 = no barriers inside it.
-template <int D, bool IC, int EPI, bool TRACE, int ABL = 0>
+// it, 4 = no barriers inside it, 8 = no counted waits inside it.  DF: a load segment issues its DMA pieces BEFORE its
+// fragment reads (A/B experiment).
+// IC: 0 = the phase's two DMA pieces at the end of the load segment; 1 = between the MFMAs of the compute segment (behind
+// the 4th and the 12th, every wave alike); 2 = between the MFMAs, each of the four computing waves at its own place
+// (behind MFMA 2 wn + 1 and 2 wn + 9), so that no two pieces are offered to the CU's texture-address path at once.
+template <int D, int IC, int EPI, bool TRACE, int ABL = 0, bool DF = false>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                             const float* __restrict__ bias, bf16_t* C, long M, int N,
                                                             int K, long lda, long ldw, long ldc, int nblk,
                                                             uint32_t* __restrict__ trace, int stagger) {
-    static_assert((D == 5 && !IC) || (D == 6 && IC), "wait counts below are written for these two schedules");
+    static_assert((D == 5 && !IC) || (D == 6 && IC), "wait counts below are written for these schedules");
     __shared__ __attribute__((aligned(1024))) char lds[RING + EXTRA];
     float* lds_bias = reinterpret_cast<float*>(lds + RING);
     uint32_t* lds_trace = reinterpret_cast<uint32_t*>(lds + RING);
@@ -183,30 +187,56 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         acc[2 * (nh) + (b_)][4 * (mh) + mb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
             WF[b_][k_], AF[mb_][k_], acc[2 * (nh) + (b_)][4 * (mh) + mb_], 0, 0, 0);
 
+#define GB_MFMA1(WF, mh, nh, b_, k_, mb_)                                                  \
+    acc[2 * (nh) + (b_)][4 * (mh) + (mb_)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(     \
+        WF[b_][k_], AF[mb_][k_], acc[2 * (nh) + (b_)][4 * (mh) + (mb_)], 0, 0, 0);
+    // two MFMAs, then (IC == 2) the piece `pc` of the phase's half-tile if this is wave column `slot`'s turn
+#define GB_MFMA2_HOOK(WF, mh, nh, b_, k_, mb0, issue, j, tp, slot, pc)                    \
+    GB_MFMA1(WF, mh, nh, b_, k_, mb0)                                                      \
+    if (IC == 2 && (issue) && !(ABL & 1)) {                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+        if (wn == (slot)) GB_ISSUE1(j, tp, pc)                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                 \
+    }                                                                                      \
+    GB_MFMA1(WF, mh, nh, b_, k_, (mb0) + 1)
+#define GB_MFMA16_STAGGERED(WF, mh, nh, issue, j, tp)                                      \
+    GB_MFMA2_HOOK(WF, mh, nh, 0, 0, 0, issue, j, tp, 0, 0)                                 \
+    GB_MFMA2_HOOK(WF, mh, nh, 0, 0, 2, issue, j, tp, 1, 0)                                 \
+    GB_MFMA2_HOOK(WF, mh, nh, 1, 0, 0, issue, j, tp, 2, 0)                                 \
+    GB_MFMA2_HOOK(WF, mh, nh, 1, 0, 2, issue, j, tp, 3, 0)                                 \
+    GB_MFMA2_HOOK(WF, mh, nh, 0, 1, 0, issue, j, tp, 0, 1)                                 \
+    GB_MFMA2_HOOK(WF, mh, nh, 0, 1, 2, issue, j, tp, 1, 1)                                 \
+    GB_MFMA2_HOOK(WF, mh, nh, 1, 1, 0, issue, j, tp, 2, 1)                                 \
+    GB_MFMA2_HOOK(WF, mh, nh, 1, 1, 2, issue, j, tp, 3, 1)
+
     // end of a load segment: [IC = false: DMA issue,] counted wait, barrier; then the compute segment -- 16 MFMAs,
     // IC = true: with the phase's two pieces behind the 4th and the 12th -- and the closing barrier
 #define GB_PHASE(WF, mh, nh, issue, j, tp, vm)                                             \
     __builtin_amdgcn_sched_barrier(0);                                                     \
-    if (!IC && (issue) && !(ABL & 1)) GB_ISSUE(j, tp)                                      \
-    GB_WAIT(vm);                                                                           \
+    if (!IC && !DF && (issue) && !(ABL & 1)) GB_ISSUE(j, tp)                               \
+    if (!(ABL & 8)) GB_WAIT(vm);                                                           \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     GB_STAMP()                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                         \
+    if (IC == 2) {                                                                         \
+        GB_MFMA16_STAGGERED(WF, mh, nh, issue, j, tp)                                      \
+    } else {                                                                               \
     GB_MFMA4(WF, mh, nh, 0, 0)                                                             \
-    if (IC && (issue) && !(ABL & 1)) {                                                     \
+    if (IC == 1 && (issue) && !(ABL & 1)) {                                                \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         GB_ISSUE1(j, tp, 0)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }                                                                                      \
     GB_MFMA4(WF, mh, nh, 1, 0)                                                             \
     GB_MFMA4(WF, mh, nh, 0, 1)                                                             \
-    if (IC && (issue) && !(ABL & 1)) {                                                     \
+    if (IC == 1 && (issue) && !(ABL & 1)) {                                                \
         __builtin_amdgcn_sched_barrier(0);                                                 \
         GB_ISSUE1(j, tp, 1)                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                 \
     }                                                                                      \
     GB_MFMA4(WF, mh, nh, 1, 1)                                                             \
+    }                                                                                      \
     __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                          \
@@ -218,18 +248,22 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 #define GB_KTILE(t, i1, i2, i3, i4, v1, v2, v3, v4, last)                                                  \
     {                                                                                                      \
         /* phase 1: quadrant (rows half 0, columns half 0); its k-step 0 A fragments were read a phase ago */ \
+        if (DF && !IC && (i1) && !(ABL & 1)) GB_ISSUE((D + 0) & 3, (t) + ((D + 0) >> 2))                   \
         _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) AF[mb_][0] = AN[mb_];                          \
         GB_READ_A(AF, 0, 1)                                                                                \
         GB_READ_W(WF0, 0)                                                                                  \
         GB_PHASE(WF0, 0, 0, i1, (D + 0) & 3, (t) + ((D + 0) >> 2), v1)                                     \
         /* phase 2: (rows half 0, columns half 1) */                                                       \
+        if (DF && !IC && (i2) && !(ABL & 1)) GB_ISSUE((D + 1) & 3, (t) + ((D + 1) >> 2))                   \
         GB_READ_W(WF1, 1)                                                                                  \
         GB_PHASE(WF1, 0, 1, i2, (D + 1) & 3, (t) + ((D + 1) >> 2), v2)                                     \
         /* phase 3: (rows half 1, columns half 1) */                                                       \
+        if (DF && !IC && (i3) && !(ABL & 1)) GB_ISSUE((D + 2) & 3, (t) + ((D + 2) >> 2))                   \
         GB_READ_A(AF, 1, 0)                                                                                \
         GB_READ_A(AF, 1, 1)                                                                                \
         GB_PHASE(WF1, 1, 1, i3, (D + 2) & 3, (t) + ((D + 2) >> 2), v3)                                     \
         /* phase 4: (rows half 1, columns half 0); W half 0 is still in registers */                       \
+        if (DF && !IC && (i4) && !(ABL & 1)) GB_ISSUE((D + 3) & 3, (t) + ((D + 3) >> 2))                   \
         if (!(last) && !(ABL & 2)) { GB_READ_AN(bufo ^ (4 * HALF)) }                                       \
         GB_PHASE(WF0, 1, 0, i4, (D + 3) & 3, (t) + ((D + 3) >> 2), v4)                                     \
         bufo ^= 4 * HALF;                                                                                  \
@@ -440,6 +474,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 #undef GB_KTILE
 #undef GB_PHASE
 #undef GB_MFMA4
+#undef GB_MFMA1
+#undef GB_MFMA2_HOOK
+#undef GB_MFMA16_STAGGERED
 #undef GB_READ_W
 #undef GB_READ_A
 #undef GB_READ_W_
@@ -466,7 +503,9 @@ extern "C" {
  * schedule (pieces issued between the MFMAs of the compute segment, 6 half-tiles ahead, instead of at the end of the load
  * segment, 5 ahead).  Bits 1-3: start stagger of the workgroups, in eighths of a tile period (default 0).  Bits 4-6
  * (bias-free, non-accumulating launches only): timing experiments with WRONG results -- 1 no DMA pieces, 2 no fragment
- * reads, 4 no barriers inside the main loop.  Bits 8-15: at most that many x 8 workgroups (0: one per CU).
+ * reads, 4 no barriers inside the main loop.  Bits 8-15: at most that many x 8 workgroups (0: one per CU).  Bit 16:
+ * no counted waits inside the main loop (wrong results).  Bit 17: DMA pieces issued before the fragment reads.  Bit 18:
+ * DMA pieces between the MFMAs, each computing wave at its own place.
  * trace != NULL (8192 uint32 of device memory): the next bias-free, non-accumulating launches run the diagnostic build,
  * which leaves the s_memtime stamps of workgroup 0's second tile there (8 waves x 1024). */
 int cwlt_gemm_bf16_tune(int variant, void* trace) {
@@ -530,23 +569,28 @@ int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int
         case 2: kfn = gb::gemm_bf16_kernel<D_, IC_, 2, false>; break;                           \
         default: kfn = gb::gemm_bf16_kernel<D_, IC_, 3, false>; break;                          \
     }
-    if (var & 1) {
-        GB_PICK(6, true)
+    if (var & (1 << 18)) {
+        GB_PICK(6, 2)
+    } else if (var & 1) {
+        GB_PICK(6, 1)
     } else {
-        GB_PICK(5, false)
+        GB_PICK(5, 0)
     }
 #undef GB_PICK
     if (epi == 0 && !tr && abl) {
         switch (abl) {
-            case 1: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 1>; break;
-            case 2: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 2>; break;
-            case 3: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 3>; break;
-            case 4: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 4>; break;
-            case 5: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 5>; break;
-            case 6: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 6>; break;
-            default: kfn = gb::gemm_bf16_kernel<5, false, 0, false, 7>; break;
+            case 1: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 1>; break;
+            case 2: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 2>; break;
+            case 3: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 3>; break;
+            case 4: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 4>; break;
+            case 5: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 5>; break;
+            case 6: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 6>; break;
+            default: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 7>; break;
         }
     }
+    if (epi == 0 && !tr && (var & (1 << 16))) kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 8>;
+    if (epi == 0 && !tr && (var & (1 << 17))) kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 0, true>;
+    if (epi == 1 && !tr && (var & (1 << 17))) kfn = gb::gemm_bf16_kernel<5, 0, 1, false, 0, true>;
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
                        bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc, (int)nblk, tr, stagger);
     return (int)hipGetLastError();

@@ -104,6 +104,10 @@ def ablate(M, N, K, rounds):
     for ab in range(8):
         t = sorted(ts[ab])[len(ts[ab]) // 2]
         print("  %-36s %8.1f us (%5.0f TF-equivalent)" % (names[ab], t * 1e3, fl / t / 1e9))
+    ts = time_rounds([run(0), run(1 << 16), run(1 << 17)], rounds)
+    for nm, t_ in zip(("everything (again)", "no counted waits in the loop", "DMA pieces before the fragment reads"), ts):
+        t = sorted(t_)[len(t_) // 2]
+        print("  %-36s %8.1f us (%5.0f TF-equivalent)" % (nm, t * 1e3, fl / t / 1e9))
     print("start stagger (eighths of a tile period over 16 groups of workgroups):")
     ts = time_rounds([run(sg << 1) for sg in range(8)], rounds)
     for sg in range(8):
