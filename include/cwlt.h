@@ -207,11 +207,12 @@ int cwlt_gemm_nt_bias_dropout_add_layernorm(const void* a, const void* w, const 
  * 16-byte aligned pointers (N <= 8192 with a bias: the strip is kept in LDS).  Persistent: one workgroup per CU walks the
  * tiles, the next tile's first operand pieces are requested before this tile's stores.
  * cwlt_gemm_bf16_tune(variant, trace): A/B and diagnostic switches (tools/bench_gemm.py); variant < 0: default.  Bit 0:
- * the other DMA schedule (pieces between the MFMAs, 6 half-tiles ahead, instead of at the end of the load segment, 5
- * ahead); bits 1-3: start stagger of the workgroups in eighths of a tile period; bits 4-6: timing experiments with WRONG
- * results on bias-free, non-accumulating launches (1 no DMA, 2 no fragment reads, 4 no barriers in the main loop);
- * bits 8-15: at most that many x 8 workgroups.  trace != NULL (8192 uint32 of device memory): bias-free,
- * non-accumulating launches run the diagnostic build and leave workgroup 0's s_memtime stamps of its second tile there. */
+ * the next tile's first operands are requested after the main loop instead of from inside its last K-tile; bits 1-3:
+ * start stagger of the workgroups in eighths of a tile period (default: 4 for K <= 1024, else 0); bits 4-7: timing
+ * experiments with WRONG results on bias-free, non-accumulating launches (1 no DMA, 2 no fragment reads, 4 no barriers,
+ * 8 no counted waits in the main loop); bits 8-15: at most that many x 8 workgroups.  trace != NULL (8192 uint32 of
+ * device memory): bias-free, non-accumulating launches run the diagnostic build and leave workgroup 0's s_memtime stamps
+ * of its second tile there. */
 int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int64_t lda,
                    int64_t ldw, int64_t ldc, int accumulate, void* stream);
 int cwlt_gemm_bf16_tune(int variant, void* trace);

@@ -25,11 +25,11 @@
 //   * DMA pieces run D half-tiles ahead of their use and are never drained inside the loop: each load segment ends with
 //     a counted `s_waitcnt vmcnt`, which retires exactly the pieces the NEXT phase reads; a slot is rewritten at the
 //     earliest two phases after its last read (one phase for the staggered half, one for its reads to return).  The two
-//     pieces a wave issues per phase go out either at the end of its load segment (IC = false) or BETWEEN the MFMAs of
-//     its compute segment (IC = true: the four waves of a load segment otherwise queue their pieces at the CU's one
-//     texture-address path at the same moment, and the compute waves wait for them at the barrier);
-//   * the next tile's first D half-tiles are requested BEFORE this tile's epilogue, so the stores of one tile and the
-//     load latency of the next overlap; the stores are buffer stores (row / column edges by the hardware range check: no
+//     pieces a wave issues per phase go out at the END of its load segment (between the MFMAs of the compute segment they
+//     cost 4-25 %: profiles/r04_gemm_dma_placement.txt);
+//   * the next tile's first four half-tiles are requested from inside this tile's LAST K-tile (its successor starts in
+//     the buffer that K-tile leaves free), the fifth before the epilogue: the stores of one tile and the load latency of
+//     the next overlap; the stores are buffer stores (row / column edges by the hardware range check: no
 //     branch, always 16 per lane) so that the counted waits of the next tile can step over them (vmcnt counts loads,
 //     stores and LDS-DMA together, in issue order); the bias strip sits in LDS (a vector load in the epilogue would make
 //     the compiler drain the DMA pieces in flight);
@@ -84,17 +84,15 @@ typedef __attribute__((address_space(3))) void lds_void;
 
 // EPI bits: 1 = bias, 2 = accumulate onto C.  TRACE: s_memtime stamps of one tile's segments (diagnostic build).
 // ABL (timing experiments only, results are wrong): 1 = no DMA pieces inside the main loop, 2 = no fragment reads inside
-// it, 4 = no barriers inside it, 8 = no counted waits inside it.  DF: a load segment issues its DMA pieces BEFORE its
-// fragment reads (A/B experiment).
-// IC: 0 = the phase's two DMA pieces at the end of the load segment; 1 = between the MFMAs of the compute segment (behind
-// the 4th and the 12th, every wave alike); 2 = between the MFMAs, each of the four computing waves at its own place
-// (behind MFMA 2 wn + 1 and 2 wn + 9), so that no two pieces are offered to the CU's texture-address path at once.
-template <int D, int IC, int EPI, bool TRACE, int ABL = 0, bool DF = false>
+// it, 4 = no barriers inside it, 8 = no counted waits inside it.
+// EP: the next tile's first four half-tiles are requested from inside this tile's LAST K-tile (one per phase) instead of
+// after the main loop.
+template <int EPI, bool TRACE, int ABL = 0, bool EP = true>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                             const float* __restrict__ bias, bf16_t* C, long M, int N,
                                                             int K, long lda, long ldw, long ldc, int nblk,
                                                             uint32_t* __restrict__ trace, int stagger) {
-    static_assert((D == 5 && !IC) || (D == 6 && IC), "wait counts below are written for these schedules");
+    constexpr int D = 5;           // half-tiles a DMA piece is issued ahead of its use
     __shared__ __attribute__((aligned(1024))) char lds[RING + EXTRA];
     float* lds_bias = reinterpret_cast<float*>(lds + RING);
     uint32_t* lds_trace = reinterpret_cast<uint32_t*>(lds + RING);
@@ -125,25 +123,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
     const uint32_t lds_w = (uint32_t)(uintptr_t)(lds_void*)lds + w * 2048;      // this wave's rows inside a slot
 
-    // half-tile g = 4 t + j (j = 0: A half 0, 1: W half 0, 2: W half 1, 3: A half 1) lives in slot g & 7
-#define GB_LA(j, tp) (lds_w + (uint32_t)((((tp) & 1) * 4 + (j)) * HALF))
-#define GB_ISSUE(j, tp)                                                                   \
+    // half-tile g = 4 t + j (j = 0: A half 0, 1: W half 0, 2: W half 1, 3: A half 1) of a tile whose K-tile 0 sits in
+    // buffer `pr` lives in slot 4 ((t + pr) & 1) + j
+#define GB_ISSUE(j, tp, pr)                                                               \
     {                                                                                     \
-        const uint32_t la = GB_LA(j, tp);                                                 \
+        const uint32_t la = lds_w + (uint32_t)(((((tp) + (pr)) & 1) * 4 + (j)) * HALF);   \
         const uint32_t so = (uint32_t)(tp) * (BK * 2);                                    \
         if ((j) == 0) GB_DMA2(a_voff[0][0], a_voff[0][1], ars, la, so)                    \
         else if ((j) == 1) GB_DMA2(w_voff[0][0], w_voff[0][1], wrs, la, so)               \
         else if ((j) == 2) GB_DMA2(w_voff[1][0], w_voff[1][1], wrs, la, so)               \
         else GB_DMA2(a_voff[1][0], a_voff[1][1], ars, la, so)                             \
-    }
-#define GB_ISSUE1(j, tp, i)                                                               \
-    {                                                                                     \
-        const uint32_t la = GB_LA(j, tp) + (i) * 1024;                                    \
-        const uint32_t so = (uint32_t)(tp) * (BK * 2);                                    \
-        if ((j) == 0) GB_DMA1(a_voff[0][i], ars, la, so)                                  \
-        else if ((j) == 1) GB_DMA1(w_voff[0][i], wrs, la, so)                             \
-        else if ((j) == 2) GB_DMA1(w_voff[1][i], wrs, la, so)                             \
-        else GB_DMA1(a_voff[1][i], ars, la, so)                                           \
     }
 
     // ---- fragment side.  MFMA 16x16x32: lane l holds operand row l & 15, k = 8 (l >> 4) + j of a 32-wide k-step.
@@ -159,7 +148,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         w_off[k] = (32 * wn + 8 * (l15 >> 2) + (l15 & 3)) * 128 + pos;
     }
 
-    bf16x8 AF[4][2], WF0[2][2], WF1[2][2], AN[4];
+    bf16x8 AF[4][2], WF0[2][2], WF1[2][2];
     f32x4 acc[4][8];               // [column tile nb][row tile mb]
     int bufo = 0;                  // slot offset of the current K-tile's buffer, toggled every K-tile
     int tq = 0;                    // trace: stamp index
@@ -174,9 +163,6 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
     _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                    \
         dst[mb_][k] = GB_FRAG(bufo + ((mh) ? 3 : 0) * HALF + a_off[k] + mb_ * 2048);
 #define GB_READ_A(dst, mh, k) if (!(ABL & 2)) { GB_READ_A_(dst, mh, k) }
-#define GB_READ_AN(bufn)                                                                   \
-    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                    \
-        AN[mb_] = GB_FRAG((bufn) + a_off[0] + mb_ * 2048);
 #define GB_READ_W_(dst, nh)                                                                \
     _Pragma("unroll") for (int k_ = 0; k_ < 2; ++k_)                                       \
         _Pragma("unroll") for (int b_ = 0; b_ < 2; ++b_)                                   \
@@ -187,94 +173,63 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         acc[2 * (nh) + (b_)][4 * (mh) + mb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(    \
             WF[b_][k_], AF[mb_][k_], acc[2 * (nh) + (b_)][4 * (mh) + mb_], 0, 0, 0);
 
-#define GB_MFMA1(WF, mh, nh, b_, k_, mb_)                                                  \
-    acc[2 * (nh) + (b_)][4 * (mh) + (mb_)] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(     \
-        WF[b_][k_], AF[mb_][k_], acc[2 * (nh) + (b_)][4 * (mh) + (mb_)], 0, 0, 0);
-    // two MFMAs, then (IC == 2) the piece `pc` of the phase's half-tile if this is wave column `slot`'s turn
-#define GB_MFMA2_HOOK(WF, mh, nh, b_, k_, mb0, issue, j, tp, slot, pc)                    \
-    GB_MFMA1(WF, mh, nh, b_, k_, mb0)                                                      \
-    if (IC == 2 && (issue) && !(ABL & 1)) {                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        if (wn == (slot)) GB_ISSUE1(j, tp, pc)                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-    }                                                                                      \
-    GB_MFMA1(WF, mh, nh, b_, k_, (mb0) + 1)
-#define GB_MFMA16_STAGGERED(WF, mh, nh, issue, j, tp)                                      \
-    GB_MFMA2_HOOK(WF, mh, nh, 0, 0, 0, issue, j, tp, 0, 0)                                 \
-    GB_MFMA2_HOOK(WF, mh, nh, 0, 0, 2, issue, j, tp, 1, 0)                                 \
-    GB_MFMA2_HOOK(WF, mh, nh, 1, 0, 0, issue, j, tp, 2, 0)                                 \
-    GB_MFMA2_HOOK(WF, mh, nh, 1, 0, 2, issue, j, tp, 3, 0)                                 \
-    GB_MFMA2_HOOK(WF, mh, nh, 0, 1, 0, issue, j, tp, 0, 1)                                 \
-    GB_MFMA2_HOOK(WF, mh, nh, 0, 1, 2, issue, j, tp, 1, 1)                                 \
-    GB_MFMA2_HOOK(WF, mh, nh, 1, 1, 0, issue, j, tp, 2, 1)                                 \
-    GB_MFMA2_HOOK(WF, mh, nh, 1, 1, 2, issue, j, tp, 3, 1)
-
-    // end of a load segment: [IC = false: DMA issue,] counted wait, barrier; then the compute segment -- 16 MFMAs,
-    // IC = true: with the phase's two pieces behind the 4th and the 12th -- and the closing barrier
-#define GB_PHASE(WF, mh, nh, issue, j, tp, vm)                                             \
+    // end of a load segment: the phase's two DMA pieces, counted wait, barrier; then the compute segment -- 16 MFMAs --
+    // and the closing barrier.  (Pieces issued BETWEEN the MFMAs instead -- every wave behind its 4th and 12th, or each
+    // of the four computing waves at its own place -- cost 4-25 % on every shape: a wave cannot issue a vector-memory
+    // instruction without holding up the MFMAs behind it.  profiles/r04_gemm_dma_placement.txt)
+#define GB_PHASE(WF, mh, nh, issue, j, tp, pr, vm, vm0)                                    \
     __builtin_amdgcn_sched_barrier(0);                                                     \
-    if (!IC && !DF && (issue) && !(ABL & 1)) GB_ISSUE(j, tp)                               \
-    if (!(ABL & 8)) GB_WAIT(vm);                                                           \
+    if (issue) {              /* compile-time true / false, or one wave-uniform branch (the last K-tile) */ \
+        if (!(ABL & 1)) GB_ISSUE(j, tp, pr)                                                \
+        if (!(ABL & 8) && (vm) < 32) GB_WAIT(vm);                                          \
+    } else {                                                                               \
+        if (!(ABL & 8) && (vm0) < 32) GB_WAIT(vm0);                                        \
+    }                                                                                      \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     GB_STAMP()                                                                             \
     __builtin_amdgcn_s_setprio(1);                                                         \
-    if (IC == 2) {                                                                         \
-        GB_MFMA16_STAGGERED(WF, mh, nh, issue, j, tp)                                      \
-    } else {                                                                               \
     GB_MFMA4(WF, mh, nh, 0, 0)                                                             \
-    if (IC == 1 && (issue) && !(ABL & 1)) {                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        GB_ISSUE1(j, tp, 0)                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-    }                                                                                      \
     GB_MFMA4(WF, mh, nh, 1, 0)                                                             \
     GB_MFMA4(WF, mh, nh, 0, 1)                                                             \
-    if (IC == 1 && (issue) && !(ABL & 1)) {                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-        GB_ISSUE1(j, tp, 1)                                                                \
-        __builtin_amdgcn_sched_barrier(0);                                                 \
-    }                                                                                      \
     GB_MFMA4(WF, mh, nh, 1, 1)                                                             \
-    }                                                                                      \
     __builtin_amdgcn_s_setprio(0);                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     if (!(ABL & 4)) __builtin_amdgcn_s_barrier();                                          \
     __builtin_amdgcn_sched_barrier(0);                                                     \
     GB_STAMP()
 
-    // One K-tile.  i1..i4: whether phase p still issues a half-tile (g = 4 t + p - 1 + D < 4 nK); v1..v4: the counted
-    // waits; last: no next K-tile to pre-read from.
-#define GB_KTILE(t, i1, i2, i3, i4, v1, v2, v3, v4, last)                                                  \
+    // One K-tile.  Phase p issues half-tile g0 + p - 1 counted from K-tile t (g0 = D inside a tile; g0 = 0 with t = 0
+    // and the NEXT tile's buffer parity for the pieces a tile's last K-tile requests for its successor); i1..i4: whether
+    // it issues at all (compile-time, or one wave-uniform condition); v1..v4: the counted waits behind an issue, u1..u4
+    // without one (>= 32: none).
+#define GB_KTILE(t, g0, pr, i1, i2, i3, i4, v1, v2, v3, v4, u1, u2, u3, u4)                               \
     {                                                                                                      \
-        /* phase 1: quadrant (rows half 0, columns half 0); its k-step 0 A fragments were read a phase ago */ \
-        if (DF && !IC && (i1) && !(ABL & 1)) GB_ISSUE((D + 0) & 3, (t) + ((D + 0) >> 2))                   \
-        _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_) AF[mb_][0] = AN[mb_];                          \
+        /* the buffer offset is made opaque per K-tile: knowing how it runs from one peeled K-tile to the  */ \
+        /* next, hipcc hoists every (offset + lane address) sum out of them and spills 30 registers        */ \
+        asm volatile("" : "+s"(bufo));                                                                     \
+        /* phase 1: quadrant (rows half 0, columns half 0) */                                              \
+        GB_READ_A(AF, 0, 0)                                                                                \
         GB_READ_A(AF, 0, 1)                                                                                \
         GB_READ_W(WF0, 0)                                                                                  \
-        GB_PHASE(WF0, 0, 0, i1, (D + 0) & 3, (t) + ((D + 0) >> 2), v1)                                     \
+        GB_PHASE(WF0, 0, 0, i1, ((g0) + 0) & 3, (t) + (((g0) + 0) >> 2), pr, v1, u1)                       \
         /* phase 2: (rows half 0, columns half 1) */                                                       \
-        if (DF && !IC && (i2) && !(ABL & 1)) GB_ISSUE((D + 1) & 3, (t) + ((D + 1) >> 2))                   \
         GB_READ_W(WF1, 1)                                                                                  \
-        GB_PHASE(WF1, 0, 1, i2, (D + 1) & 3, (t) + ((D + 1) >> 2), v2)                                     \
+        GB_PHASE(WF1, 0, 1, i2, ((g0) + 1) & 3, (t) + (((g0) + 1) >> 2), pr, v2, u2)                       \
         /* phase 3: (rows half 1, columns half 1) */                                                       \
-        if (DF && !IC && (i3) && !(ABL & 1)) GB_ISSUE((D + 2) & 3, (t) + ((D + 2) >> 2))                   \
         GB_READ_A(AF, 1, 0)                                                                                \
         GB_READ_A(AF, 1, 1)                                                                                \
-        GB_PHASE(WF1, 1, 1, i3, (D + 2) & 3, (t) + ((D + 2) >> 2), v3)                                     \
+        GB_PHASE(WF1, 1, 1, i3, ((g0) + 2) & 3, (t) + (((g0) + 2) >> 2), pr, v3, u3)                       \
         /* phase 4: (rows half 1, columns half 0); W half 0 is still in registers */                       \
-        if (DF && !IC && (i4) && !(ABL & 1)) GB_ISSUE((D + 3) & 3, (t) + ((D + 3) >> 2))                   \
-        if (!(last) && !(ABL & 2)) { GB_READ_AN(bufo ^ (4 * HALF)) }                                       \
-        GB_PHASE(WF0, 1, 0, i4, (D + 3) & 3, (t) + ((D + 3) >> 2), v4)                                     \
+        GB_PHASE(WF0, 1, 0, i4, ((g0) + 3) & 3, (t) + (((g0) + 3) >> 2), pr, v4, u4)                       \
         bufo ^= 4 * HALF;                                                                                  \
     }
 
-    // Counted waits (S = steady state).  With the pieces issued at the END of the load segment (IC = false) the wait
-    // of phase P leaves D - 2 half-tiles in flight; issued inside the compute segment (IC = true) they are one phase
-    // younger and D - 3 are left: 2 x 3 = 6 pieces for both schedules built.  In the FIRST K-tile of a tile the 16
-    // stores of the previous tile's epilogue sit in the queue behind the D prologue half-tiles: while the half-tile a
-    // phase waits for (P + 1) is one of those (P <= D - 2) the stores are allowed to stay outstanding as well (+ 16).
-    constexpr int S = 6, SF = S + 16;
+    // Counted waits.  The wait that ends phase P's load segment must retire half-tile P + 1 and may leave the D - 2
+    // half-tiles behind it in flight: S = 2 (D - 2) = 6 pieces in steady state.  In the FIRST K-tile of a tile the 16
+    // stores of the previous tile's epilogue sit in the queue behind that tile's last requests: while the half-tile
+    // waited for is older than the stores (P <= D - 2 = 3) they may stay outstanding too (+ 16).
+    constexpr int S = 2 * (D - 2), SF = S + 16, NONE = 63;
 
     // bias strip -> LDS, once per workgroup (read back in every epilogue without touching the vector-memory queue)
     if (EPI & 1) {
@@ -303,8 +258,13 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         wrs[1] = __builtin_amdgcn_readfirstlane((uint32_t)(wb_ >> 32));                                     \
         wrs[2] = __builtin_amdgcn_readfirstlane((uint32_t)(((long)(nr_ - 1) * ldw + K) * 2));               \
     }
-#define GB_PROLOGUE()                                                                      \
-    _Pragma("unroll") for (int g = 0; g < D; ++g) GB_ISSUE(g & 3, g >> 2)
+#define GB_NEXT(from, nx)                                                                  \
+    int nx = (from) + gridDim.x;                                                           \
+    while (nx < nblk) {            /* padding tiles (row tiles are dealt in eights) hold no rows */ \
+        GB_TILE(nx, mc_, nc_)                                                              \
+        if (mc_ < M) break;                                                                \
+        nx += gridDim.x;                                                                   \
+    }
 
     // Every workgroup takes the same time per tile, so left alone the whole chip stores its 256 x 128 KiB of output and
     // requests the next tiles' first operands in the same few microseconds and then leaves HBM idle for a main loop.
@@ -313,81 +273,73 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
     if (stagger) {
         for (int left = ((blockIdx.x >> 3) & 15) * stagger; left > 0; left -= 64) __builtin_amdgcn_s_sleep(64);
     }
-    int idx = blockIdx.x;
-    while (idx < nblk) {           // padding tiles (row tiles are dealt in eights) hold no rows
-        GB_TILE(idx, mc_, nc_)
-        if (mc_ < M) break;
-        idx += gridDim.x;
-    }
+    GB_NEXT((int)blockIdx.x - (int)gridDim.x, idx)
     if (idx >= nblk) return;
+    int par = 0;                   // buffer of the current tile's K-tile 0
     {
         GB_TILE(idx, m0p, n0p)
         GB_DESC(m0p, n0p)
         __syncthreads();           // the bias strip is in LDS (and its loads are behind us)
-        GB_PROLOGUE()
+#pragma unroll
+        for (int g = 0; g < D; ++g) GB_ISSUE(g & 3, g >> 2, 0)
     }
     bool first = true;
     int it = 0;
     while (true) {
         GB_TILE(idx, m0, n0)
+        GB_NEXT(idx, nxt)
+        const bool has_next = nxt < nblk;
+        const int parn = (par + nK) & 1;                    // the next tile starts in the buffer this tile's last K-tile leaves free
         const bool tracing = TRACE && blockIdx.x == 0 && it == 1;
         GB_STAMP()
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < 8; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        bufo = 0;
+        bufo = par * 4 * HALF;
         // half-tiles 0 and 1 have landed everywhere.  A workgroup's first tile has no stores in the queue: it drains
         // its prologue once, after which the "+ 16" waits of the first K-tile hold trivially
         if (first) {
             GB_WAIT(0);
         } else {
-            GB_WAIT(2 * (D - 2) + 16);
+            GB_WAIT(SF);
         }
         first = false;
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         GB_STAMP()
-        GB_READ_AN(0)
         if (ABL & 2) {                                      // timing experiment: the fragments are read once per tile
             GB_READ_A_(AF, 0, 0) GB_READ_A_(AF, 0, 1) GB_READ_W_(WF0, 0) GB_READ_W_(WF1, 1)
         }
         if (wm) __builtin_amdgcn_s_barrier();               // waves 4-7 run one barrier behind waves 0-3
         __builtin_amdgcn_sched_barrier(0);
 
-        // phase P of G = 4 nK issues while P <= G - D; the waits of the last phases shrink with what is left in flight
+        // phase P of G = 4 nK issues half-tile P - 1 + D while that is < G; the waits of the last phases shrink with
+        // what is left in flight.  The last K-tile then requests the next tile's half-tiles 0..3 (EP), one per phase:
+        // the buffer they go to was last read a K-tile ago, and what is still in flight of THIS tile stays counted.
+        int t = 0;
         if (nK == 2) {
-            if (D == 5) {
-                GB_KTILE(0, true, true, true, false, SF, SF, SF, 4, false)
-            } else {
-                GB_KTILE(0, true, true, false, false, SF, SF, SF, 4 + 16, false)
-            }
-            GB_KTILE(1, false, false, false, false, 2, 0, 0, 0, true)
+            GB_KTILE(0, D, par, true, true, true, false, SF, SF, SF, NONE, NONE, NONE, NONE, 4)
         } else {
-            int t = 0;
-            if (D == 5) {
-                GB_KTILE(t, true, true, true, true, SF, SF, SF, S, false)
-                for (t = 1; t < nK - 2; ++t) GB_KTILE(t, true, true, true, true, S, S, S, S, false)
-                GB_KTILE(t, true, true, true, false, S, S, S, 4, false)
-            } else {
-                GB_KTILE(t, true, true, true, true, SF, SF, SF, SF, false)
-                for (t = 1; t < nK - 2; ++t) GB_KTILE(t, true, true, true, true, S, S, S, S, false)
-                GB_KTILE(t, true, true, false, false, S, S, S, 4, false)
+            GB_KTILE(0, D, par, true, true, true, true, SF, SF, SF, S, NONE, NONE, NONE, NONE)
+            for (t = 1; t < nK - 2; ++t) GB_KTILE(t, D, par, true, true, true, true, S, S, S, S, NONE, NONE, NONE, NONE)
+            GB_KTILE(t, D, par, true, true, true, false, S, S, S, NONE, NONE, NONE, NONE, 4)
+        }
+        {
+            const bool early = EP && has_next;
+            if (early) {
+                GB_TILE(nxt, m0n, n0n)
+                GB_DESC(m0n, n0n)                           // this tile's last piece went out a phase ago
             }
-            ++t;
-            GB_KTILE(t, false, false, false, false, 2, 0, 0, 0, true)
+            // ONE body for both cases (two copies of a K-tile behind an if / else made the register allocator spill the
+            // accumulators at the join): with a successor its four phases issue that tile's half-tiles 0..3 and wait
+            // for what is left of this one (4, 4, -, -); without, they wait (2, 0, 0, 0)
+            GB_KTILE(0, 0, parn, early, early, early, early, 4, 4, NONE, NONE, 2, 0, 0, 0)
         }
         if (!wm) __builtin_amdgcn_s_barrier();              // every wave has passed the same number of barriers
         __builtin_amdgcn_sched_barrier(0);
         GB_STAMP()
 
-        // ---- the next tile of this workgroup: its first D half-tiles go out now (every LDS read of this tile is done)
-        int nxt = idx + gridDim.x;
-        while (nxt < nblk) {
-            GB_TILE(nxt, mc_, nc_)
-            if (mc_ < M) break;
-            nxt += gridDim.x;
-        }
         // ---- epilogue: lane (l15, kg) holds, for row tile mb and column half q, the 8 columns 32 q + 8 kg .. + 7 of
         // row 16 mb + l15 of its wave tile: registers 0-3 of acc[2 q][mb] then of acc[2 q + 1][mb].  Buffer stores:
         // rows past the end fall outside the descriptor, columns past the end get an offset outside it.
@@ -404,7 +356,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         u32x4_t cin[8][2];
         if (EPI & 2) {
             // the residual gradient this product is added onto: requested first, waited for by hand (the compiler's
-            // own counted waits do not know about the DMA pieces in the queue), then the next tile's prologue
+            // own counted waits do not know about the DMA pieces in the queue), then the rest of the next tile's prologue
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
@@ -415,10 +367,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
                 asm volatile("s_waitcnt vmcnt(0)"
                              : "+v"(cin[mb][0]), "+v"(cin[mb][1]), "+v"(cin[mb + 1][0]), "+v"(cin[mb + 1][1])::"memory");
         }
-        if (nxt < nblk) {
-            GB_TILE(nxt, m0n, n0n)
-            GB_DESC(m0n, n0n)
-            GB_PROLOGUE()
+        // ---- the next tile of this workgroup: what is left of its first D half-tiles goes out now, before the stores
+        // (every LDS read of this tile is done; its K-tile 1 goes where this tile's last K-tile was)
+        if (has_next) {
+            if (EP) {
+#pragma unroll
+                for (int g = 4; g < D; ++g) GB_ISSUE(g & 3, g >> 2, parn)
+            } else {
+                GB_TILE(nxt, m0n, n0n)
+                GB_DESC(m0n, n0n)
+#pragma unroll
+                for (int g = 0; g < D; ++g) GB_ISSUE(g & 3, g >> 2, parn)
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
         GB_STAMP()
@@ -463,8 +423,9 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
             }
         __builtin_amdgcn_sched_barrier(0);
         GB_STAMP()
-        if (nxt >= nblk) break;
+        if (!has_next) break;
         idx = nxt;
+        par = parn;
         ++it;
     }
     if (TRACE && blockIdx.x == 0) {
@@ -474,20 +435,14 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 #undef GB_KTILE
 #undef GB_PHASE
 #undef GB_MFMA4
-#undef GB_MFMA1
-#undef GB_MFMA2_HOOK
-#undef GB_MFMA16_STAGGERED
 #undef GB_READ_W
 #undef GB_READ_A
 #undef GB_READ_W_
 #undef GB_READ_A_
-#undef GB_READ_AN
 #undef GB_ISSUE
-#undef GB_ISSUE1
-#undef GB_LA
 #undef GB_TILE
 #undef GB_DESC
-#undef GB_PROLOGUE
+#undef GB_NEXT
 #undef GB_STAMP
 }
 
@@ -499,13 +454,11 @@ static uint32_t* g_trace = nullptr;
 
 extern "C" {
 
-/* Tuning switch for A/B measurements (tools/bench_gemm.py); variant < 0 restores the default.  Bit 0: the other DMA
- * schedule (pieces issued between the MFMAs of the compute segment, 6 half-tiles ahead, instead of at the end of the load
- * segment, 5 ahead).  Bits 1-3: start stagger of the workgroups, in eighths of a tile period (default 0).  Bits 4-6
- * (bias-free, non-accumulating launches only): timing experiments with WRONG results -- 1 no DMA pieces, 2 no fragment
- * reads, 4 no barriers inside the main loop.  Bits 8-15: at most that many x 8 workgroups (0: one per CU).  Bit 16:
- * no counted waits inside the main loop (wrong results).  Bit 17: DMA pieces issued before the fragment reads.  Bit 18:
- * DMA pieces between the MFMAs, each computing wave at its own place.
+/* Tuning switch for A/B measurements (tools/bench_gemm.py); variant < 0 restores the default.  Bit 0: the next tile's
+ * first operands are requested after the main loop instead of from inside its last K-tile.  Bits 1-3: start stagger of
+ * the workgroups, in eighths of a tile period (default: 4 for K <= 1024, else 0).  Bits 4-7 (bias-free,
+ * non-accumulating launches only): timing experiments with WRONG results -- 1 no DMA pieces, 2 no fragment reads, 4 no
+ * barriers, 8 no counted waits inside the main loop.  Bits 8-15: at most that many x 8 workgroups (0: one per CU).
  * trace != NULL (8192 uint32 of device memory): the next bias-free, non-accumulating launches run the diagnostic build,
  * which leaves the s_memtime stamps of workgroup 0's second tile there (8 waves x 1024). */
 int cwlt_gemm_bf16_tune(int variant, void* trace) {
@@ -549,48 +502,40 @@ int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int
     const int var = g_variant < 0 ? 0 : g_variant;
     const int glim = ((var >> 8) & 255) * 8;
     if (glim && glim < grid) grid = glim;
-    // start stagger: (var >> 1 & 7) / 8 of a tile period (~3 500 cycles per K-tile + ~14 000 per tile) over 16 groups,
-    // in units of 64 cycles
-    // Default: half a tile period for K <= 1024 (there a tile's 128 KiB of stores + the next tile's first operands are a
-    // third of its time, and with every workgroup at the same point the chip alternates between saturating HBM and
-    // leaving it idle: 336 -> 300 us at K = N = 512, R = 524 288), none above (a K = 2048 tile is 55 us of main loop:
-    // 905 us with or without, and the stagger costs its own length once per launch).
+    // Start stagger, in units of 64 cycles per group step (16 groups; a tile period is ~3 500 cycles per K-tile +
+    // ~14 000).  Default: half a tile period for K <= 1024 (there a tile's 128 KiB of stores + the next tile's first
+    // operands are a third of its time, and with every workgroup at the same point the chip alternates between
+    // saturating HBM and leaving it idle: 336 -> 300 us at K = N = 512, R = 524 288), none above (a K = 2048 tile is
+    // 55 us of main loop: 905 us with or without, and the stagger costs its own length once per launch).
     const int stag8 = g_variant < 0 ? (K <= 1024 ? 4 : 0) : ((var >> 1) & 7);
     const int stagger = (int)(stag8 * ((K / gb::BK) * 3500L + 14000L) / (8 * 16 * 64));
-    const int abl = (var >> 4) & 7;
+    const int abl = (var >> 4) & 15;
     typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long, int,
                           uint32_t*, int);
     kfn_t kfn = nullptr;
     uint32_t* tr = (epi == 0) ? g_trace : nullptr;
-#define GB_PICK(D_, IC_)                                                                        \
-    switch (epi) {                                                                              \
-        case 0: kfn = tr ? gb::gemm_bf16_kernel<D_, IC_, 0, true> : gb::gemm_bf16_kernel<D_, IC_, 0, false>; break; \
-        case 1: kfn = gb::gemm_bf16_kernel<D_, IC_, 1, false>; break;                           \
-        case 2: kfn = gb::gemm_bf16_kernel<D_, IC_, 2, false>; break;                           \
-        default: kfn = gb::gemm_bf16_kernel<D_, IC_, 3, false>; break;                          \
+    const bool late = var & 1;
+    switch (epi) {
+        case 0:
+            kfn = tr ? (late ? gb::gemm_bf16_kernel<0, true, 0, false> : gb::gemm_bf16_kernel<0, true, 0, true>)
+                     : (late ? gb::gemm_bf16_kernel<0, false, 0, false> : gb::gemm_bf16_kernel<0, false, 0, true>);
+            break;
+        case 1: kfn = late ? gb::gemm_bf16_kernel<1, false, 0, false> : gb::gemm_bf16_kernel<1, false, 0, true>; break;
+        case 2: kfn = late ? gb::gemm_bf16_kernel<2, false, 0, false> : gb::gemm_bf16_kernel<2, false, 0, true>; break;
+        default: kfn = late ? gb::gemm_bf16_kernel<3, false, 0, false> : gb::gemm_bf16_kernel<3, false, 0, true>; break;
     }
-    if (var & (1 << 18)) {
-        GB_PICK(6, 2)
-    } else if (var & 1) {
-        GB_PICK(6, 1)
-    } else {
-        GB_PICK(5, 0)
-    }
-#undef GB_PICK
     if (epi == 0 && !tr && abl) {
         switch (abl) {
-            case 1: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 1>; break;
-            case 2: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 2>; break;
-            case 3: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 3>; break;
-            case 4: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 4>; break;
-            case 5: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 5>; break;
-            case 6: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 6>; break;
-            default: kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 7>; break;
+            case 1: kfn = gb::gemm_bf16_kernel<0, false, 1>; break;
+            case 2: kfn = gb::gemm_bf16_kernel<0, false, 2>; break;
+            case 3: kfn = gb::gemm_bf16_kernel<0, false, 3>; break;
+            case 4: kfn = gb::gemm_bf16_kernel<0, false, 4>; break;
+            case 5: kfn = gb::gemm_bf16_kernel<0, false, 5>; break;
+            case 6: kfn = gb::gemm_bf16_kernel<0, false, 6>; break;
+            case 7: kfn = gb::gemm_bf16_kernel<0, false, 7>; break;
+            default: kfn = gb::gemm_bf16_kernel<0, false, 8>; break;
         }
     }
-    if (epi == 0 && !tr && (var & (1 << 16))) kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 8>;
-    if (epi == 0 && !tr && (var & (1 << 17))) kfn = gb::gemm_bf16_kernel<5, 0, 0, false, 0, true>;
-    if (epi == 1 && !tr && (var & (1 << 17))) kfn = gb::gemm_bf16_kernel<5, 0, 1, false, 0, true>;
     hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
                        bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc, (int)nblk, tr, stagger);
     return (int)hipGetLastError();

@@ -57,16 +57,23 @@ def test_gemm_bf16_matches_the_f64_product(cuda, M, N, K):
     _check(acc2, prod + c0.double() + bias.double())
 
 
-@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("variant", [0, 1, 0 | (1 << 8), 1 | (1 << 8), (2 << 1) | (1 << 8)])
 @pytest.mark.parametrize("K", [128, 192, 256, 320, 2048])
 def test_every_schedule_variant_and_short_reductions(cuda, variant, K):
-    """K = 128 is two K-tiles (the peeled tail alone), 192 / 320 an odd count: the slot parity and the counted waits of the
-    last two K-tiles are exercised at every length; both DMA schedules must agree with the f64 product."""
-    M, N = 777, 512
-    a, w, bias, _ = _operands(M, N, K, 100 + K, cuda)
+    """K = 128 is two K-tiles (the peeled first and last K-tile alone), 192 / 320 an odd count (the buffer a tile starts in
+    alternates from tile to tile): the slot parity and the counted waits of the first and the last two K-tiles are exercised
+    at every length, with the next tile's operands requested from inside the last K-tile (bit 0 clear, the default) and
+    after the main loop (bit 0 set), with one tile per workgroup and -- the grid held to 8 workgroups (bit 8) -- five to
+    six tiles per workgroup, padding tiles of the 8-XCD deal among them, and with a start stagger."""
+    M, N = 5000, 512
+    a, w, bias, c0 = _operands(M, N, K, 100 + K, cuda)
     _lib.load().cwlt_gemm_bf16_tune(variant, None)
-    out = ops.gemm_bf16(a.to(cuda), w.to(cuda), bias.to(cuda))
-    _check(out, a.double() @ w.double().t() + bias.double())
+    ad, wd = a.to(cuda), w.to(cuda)
+    prod = a.double() @ w.double().t()
+    _check(ops.gemm_bf16(ad, wd, bias.to(cuda)), prod + bias.double())
+    acc = c0.to(cuda)
+    ops.gemm_bf16(ad, wd, out=acc, accumulate=True)
+    _check(acc, prod + c0.double())
 
 
 def test_strided_operands_and_output_view(cuda):

@@ -104,8 +104,9 @@ def ablate(M, N, K, rounds):
     for ab in range(8):
         t = sorted(ts[ab])[len(ts[ab]) // 2]
         print("  %-36s %8.1f us (%5.0f TF-equivalent)" % (names[ab], t * 1e3, fl / t / 1e9))
-    ts = time_rounds([run(0), run(1 << 16), run(1 << 17)], rounds)
-    for nm, t_ in zip(("everything (again)", "no counted waits in the loop", "DMA pieces before the fragment reads"), ts):
+    ts = time_rounds([run(0), run(8 << 4), run(1)], rounds)
+    for nm, t_ in zip(("everything (again)", "no counted waits in the loop",
+                       "next tile's operands requested after the main loop"), ts):
         t = sorted(t_)[len(t_) // 2]
         print("  %-36s %8.1f us (%5.0f TF-equivalent)" % (nm, t * 1e3, fl / t / 1e9))
     print("start stagger (eighths of a tile period over 16 groups of workgroups):")
@@ -141,7 +142,7 @@ def main():
     lib = _lib.load()
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    print("M = %d rows; variant bit 0: DMA pieces between the MFMAs (default: at the end of the load segment); bits 1-3: start stagger in eighths of a tile" % M)
+    print("M = %d rows; variant bit 0: next tile's operands requested after the main loop (default: from inside the last K-tile); bits 1-3: start stagger in eighths of a tile (variant -1 = the shipped default)" % M)
     for name, N, K, has_bias, acc, form in SHAPES:
         a = torch.randn(M, K, device=dev).bfloat16()
         w = (torch.randn(N, K, device=dev) * 0.05).bfloat16()
