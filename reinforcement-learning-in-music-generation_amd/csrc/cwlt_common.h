@@ -217,6 +217,14 @@ int launch_colsum_finalize_multi(const float* part, float* out, long out_stride,
                                  int ncols, hipStream_t st);
 
 
+// FFN forms of the 256 x 256 persistent projection GEMM (gemm_bf16.hip), behind gemm_nt.hip's entry points at training
+// sizes.  gelu != 0: g (written) = dropout(gelu(a w^T + bias)) -> c, gd -> g;  gelu == 0: c = (a w^T) * g, part = column
+// sums of c per 256-row tile (gemm_ffn_big_tiles(M) x N floats, or NULL).
+int launch_gemm_ffn_big(int gelu, const void* a, const void* w, const float* bias, void* g, void* c, float* part,
+                        int64_t M, int N, int K, int64_t lda, int64_t ldw, uint32_t thresh, float keep_scale,
+                        uint64_t seed, const uint64_t* seed_base, hipStream_t st);
+long gemm_ffn_big_tiles(long M);
+
 // bf16 throughput path of the causal linear attention (cla_bf16.hip); row strides must be multiples of 8.
 // P = segments per stream (scan_segments: 1 unless N * H is far below the CU count), ws = scan_seg_floats(...) floats.
 int scan_segments(int N, int H, int L);

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(256) void cw_embed_proj_fwd_kernel(const int64_t* _
 // 32-id tile) pairs -- 13 at the repo's vocabularies (2 + 5 + 1 + 3 + 1 + 1) -- dealt to the waves in order, at most
 // PB_MAXU per wave; per 64-row step a wave reads the slab's 8 transposed fragments once and issues 8 MFMAs per unit.
 // (cw_embed_bwd_mfma_kernel run once per attribute reads the slab six times and builds every tile in every workgroup:
-// 0.71 ms at the bench shape; this kernel: see DESIGN 4.3a.)
+// 0.71 ms at the bench shape; this kernel: see HISTORY 4.3a.)
 constexpr int PB_NW = 4;            // waves per workgroup
 constexpr int PB_MAXU = 4;          // units per wave
 constexpr int PB_CHUNK = 1024;      // token rows whose ids (all attributes, 16 bits each) sit in LDS at a time

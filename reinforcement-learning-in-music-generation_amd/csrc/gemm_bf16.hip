@@ -38,6 +38,7 @@
 //     accumulators, no LDS round trip in the epilogue.
 // Bound: MFMA for K >= 1024 (2 M N K flop), HBM for K = 512 (M (K + N) 2 bytes [+ M N 2 with accumulate]).
 #include "cwlt_common.h"
+#include "cwlt_gelu.h"
 #include <stdlib.h>
 
 namespace cwlt {
@@ -82,16 +83,35 @@ typedef __attribute__((address_space(3))) void lds_void;
 #define GB_FRAG(off) __builtin_bit_cast(bf16x8, *reinterpret_cast<const uint4*>(lds + (off)))
 #define GB_WAIT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 
-// EPI bits: 1 = bias, 2 = accumulate onto C.  TRACE: s_memtime stamps of one tile's segments (diagnostic build).
+// EPI: 0..3 = bits 1 (bias) | 2 (accumulate onto C);
+//      EPI_GELU: x = bf16(a w^T) + bias; c = mask * keep_scale * gelu(x), g (WRITTEN) = mask * keep_scale * gelu'(x) -- the
+//                FFN forward `dropout(gelu(linear1(.)))` with the backward's factor alongside (cwlt_gemm_nt_bias_gelu_dropout);
+//      EPI_MUL:  c = bf16(a w^T) * g (g READ), part (row tiles, N) = column sums of c -- the FFN backward
+//                (cwlt_gemm_nt_mul).  Same arithmetic, rounding points and dropout stream as gemm_nt.hip's 128 x 256 kernel.
+// TRACE: s_memtime stamps of one tile's segments (diagnostic build).
 // ABL (timing experiments only, results are wrong): 1 = no DMA pieces inside the main loop, 2 = no fragment reads inside
 // it, 4 = no barriers inside it, 8 = no counted waits inside it.
 // EP: the next tile's first four half-tiles are requested from inside this tile's LAST K-tile (one per phase) instead of
 // after the main loop.
+enum { EPI_GELU = 4, EPI_MUL = 8 };
+struct FfnArgs {               // EPI_GELU / EPI_MUL only
+    bf16_t* G;                 // gd: written (GELU) / read (MUL), dense (M, N) like C
+    float* part;               // MUL: column-sum partials, (row tiles of 256) x N, or NULL
+    uint32_t thresh;
+    float keep_scale;
+    uint64_t seed;
+    const uint64_t* seed_base;
+};
+
 template <int EPI, bool TRACE, int ABL = 0, bool EP = true>
 __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                             const float* __restrict__ bias, bf16_t* C, long M, int N,
                                                             int K, long lda, long ldw, long ldc, int nblk,
-                                                            uint32_t* __restrict__ trace, int stagger) {
+                                                            uint32_t* __restrict__ trace, int stagger, FfnArgs ffn) {
+    constexpr bool BIAS = (EPI < 4 && (EPI & 1)) || EPI == EPI_GELU;
+    constexpr bool ACCUM = EPI < 4 && (EPI & 2);
+    constexpr bool CIN = ACCUM || EPI == EPI_MUL;          // a (M, N) tile is read back in the epilogue
+    constexpr int NSTORE = EPI == EPI_GELU ? 32 : EPI == EPI_MUL ? 17 : 16;   // vector stores per lane and tile
     constexpr int D = 5;           // half-tiles a DMA piece is issued ahead of its use
     __shared__ __attribute__((aligned(1024))) char lds[RING + EXTRA];
     float* lds_bias = reinterpret_cast<float*>(lds + RING);
@@ -228,13 +248,16 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
     // Counted waits.  The wait that ends phase P's load segment must retire half-tile P + 1 and may leave the D - 2
     // half-tiles behind it in flight: S = 2 (D - 2) = 6 pieces in steady state.  In the FIRST K-tile of a tile the 16
     // stores of the previous tile's epilogue sit in the queue behind that tile's last requests: while the half-tile
-    // waited for is older than the stores (P <= D - 2 = 3) they may stay outstanding too (+ 16).
-    constexpr int S = 2 * (D - 2), SF = S + 16, NONE = 63;
+    // waited for is older than the stores (P <= D - 2 = 3) they may stay outstanding too (+ 16; 32 / 17 for the FFN
+    // epilogues).
+    constexpr int S = 2 * (D - 2), SF = S + NSTORE, NONE = 63;
 
     // bias strip -> LDS, once per workgroup (read back in every epilogue without touching the vector-memory queue)
-    if (EPI & 1) {
+    if (BIAS) {
         for (int i = tid; i < N; i += 512) lds_bias[i] = bias[i];
     }
+    uint64_t seed = ffn.seed;
+    if (EPI == EPI_GELU && ffn.seed_base) seed += *ffn.seed_base;   // device-resident offset: fresh masks per graph replay
 
     u32x4_t ars, wrs;
     ars[3] = 0x00020000u;
@@ -354,14 +377,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         }
         const uint32_t c_step = (uint32_t)(16 * ldc * 2);
         u32x4_t cin[8][2];
-        if (EPI & 2) {
-            // the residual gradient this product is added onto: requested first, waited for by hand (the compiler's
-            // own counted waits do not know about the DMA pieces in the queue), then the rest of the next tile's prologue
+        if (CIN) {
+            // the residual gradient this product is added onto / the factor it is multiplied with: requested first,
+            // waited for by hand (the compiler's own counted waits do not know about the DMA pieces in the queue), then
+            // the rest of the next tile's prologue.  gd is read once: non-temporal.
+            const __amdgpu_buffer_rsrc_t irs =
+                EPI == EPI_MUL ? make_rsrc(ffn.G + m0 * ldc + n0, (uint32_t)(((mrows - 1) * ldc + ncols) * 2)) : crs;
 #pragma unroll
             for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
                 for (int q = 0; q < 2; ++q)
-                    cin[mb][q] = __builtin_amdgcn_raw_buffer_load_b128(crs, (int)(c_voff[q] + mb * c_step), 0, 0);
+                    cin[mb][q] = __builtin_amdgcn_raw_buffer_load_b128(irs, (int)(c_voff[q] + mb * c_step), 0,
+                                                                       EPI == EPI_MUL ? 2 : 0);
 #pragma unroll
             for (int mb = 0; mb < 8; mb += 2)
                 asm volatile("s_waitcnt vmcnt(0)"
@@ -383,7 +410,7 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
         __builtin_amdgcn_sched_barrier(0);
         GB_STAMP()
         float bs[2][8];
-        if (EPI & 1) {
+        if (BIAS) {
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 const int col = n0 + 64 * wn + 32 * q + 8 * kg;
@@ -394,6 +421,47 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
                 bs[q][4] = b1.x; bs[q][5] = b1.y; bs[q][6] = b1.z; bs[q][7] = b1.w;
             }
         }
+        if (EPI == EPI_GELU) {
+            // gemm_nt.hip's EPI_GELU arithmetic chunk by chunk: the pre-activation rounded to bf16, bias in f32, one
+            // v_exp per element for value and derivative (cwlt_gelu.h), the dropout keep flags of
+            // dropout_mask<8>(seed, row * N + col, thresh) as two 16-bit lane masks per hash word (keep_lanes16)
+            const __amdgpu_buffer_rsrc_t grs = make_rsrc(ffn.G + m0 * ldc + n0, (uint32_t)(((mrows - 1) * ldc + ncols) * 2));
+            const GeluK gk = gelu_consts(ffn.keep_scale);
+            const uint32_t thresh2 = ffn.thresh | (ffn.thresh << 16);
+            const uint32_t seed_key = (uint32_t)seed ^ ((uint32_t)(seed >> 32) * 0x9e3779b9u);
+#pragma unroll
+            for (int mb = 0; mb < 8; ++mb)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const uint64_t row = (uint64_t)(m0 + 128 * wm + 16 * mb + l15);
+                    const uint64_t pair = (row * (uint64_t)N + (uint64_t)(n0 + 64 * wn + 32 * q + 8 * kg)) >> 1;
+                    const uint32_t base = (uint32_t)pair * 0x9e3779b1u;
+                    const uint32_t key = seed_key ^ ((uint32_t)(pair >> 32) * 0x85ebca6bu);
+                    u32x4_t r, dq;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const int i0 = 2 * c, i1 = 2 * c + 1;
+                        const float a0 = i0 < 4 ? acc[2 * q][mb][i0] : acc[2 * q + 1][mb][i0 - 4];
+                        const float a1 = i1 < 4 ? acc[2 * q][mb][i1] : acc[2 * q + 1][mb][i1 - 4];
+                        f32x2 x;
+                        x[0] = (float)(__bf16)a0 + bs[q][i0];
+                        x[1] = (float)(__bf16)a1 + bs[q][i1];
+                        f32x2 y, dy;
+                        gelu_scaled2(x, gk, y, dy);
+                        const uint32_t hw = keep_lanes16(hash32((base + (uint32_t)c * 0x9e3779b1u) ^ key), thresh2);
+                        r[c] = f32x2_to_bf16x2(y[0], y[1]) & hw;
+                        dq[c] = f32x2_to_bf16x2(dy[0], dy[1]) & hw;
+                    }
+                    // g is the next GEMM's operand: default policy; gd waits for the backward: streamed past the caches
+                    __builtin_amdgcn_raw_buffer_store_b128(r, crs, (int)(c_voff[q] + mb * c_step), 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(dq, grs, (int)(c_voff[q] + mb * c_step), 0, 2);
+                }
+        } else {
+        float cs[2][8];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cs[q][j] = 0.f;
 #pragma unroll
         for (int mb = 0; mb < 8; ++mb)
 #pragma unroll
@@ -404,23 +472,65 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
                     v[r] = acc[2 * q][mb][r];
                     v[4 + r] = acc[2 * q + 1][mb][r];
                 }
-                if (EPI & 2) {
+                if (ACCUM) {
                     float o[8];
                     load8(reinterpret_cast<const bf16_t*>(&cin[mb][q]), o);
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += o[j];
                 }
-                if (EPI & 1) {
+                if (BIAS) {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) v[j] += bs[q][j];
+                }
+                if (EPI == EPI_MUL) {
+                    // the product rounded to bf16 first (what the unfused GEMM wrote), multiplied in f32, rounded once
+                    // more: the arithmetic of the two-kernel path; rows past the end read gd back as zero
+                    float o[8];
+                    load8(reinterpret_cast<const bf16_t*>(&cin[mb][q]), o);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        v[j] = (float)(__bf16)v[j] * o[j];
+                        cs[q][j] += v[j];
+                    }
                 }
                 u32x4_t pk;
                 pk[0] = f32x2_to_bf16x2(v[0], v[1]);
                 pk[1] = f32x2_to_bf16x2(v[2], v[3]);
                 pk[2] = f32x2_to_bf16x2(v[4], v[5]);
                 pk[3] = f32x2_to_bf16x2(v[6], v[7]);
-                __builtin_amdgcn_raw_buffer_store_b128(pk, crs, (int)(c_voff[q] + mb * c_step), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(pk, crs, (int)(c_voff[q] + mb * c_step), 0, EPI == EPI_MUL ? 2 : 0);
             }
+        if (EPI == EPI_MUL) {
+            // column sums of the tile (the upstream Linear's bias gradient): 8 rows per lane above, the 16 lanes of a
+            // row group by DPP, the two row halves of the tile through LDS (the bias strip's place), fixed order.  EVERY
+            // wave issues the one store (lanes without a column point outside the descriptor): the counted waits of the
+            // next tile step over a fixed number of stores.
+            float* red = lds_bias;
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    float x = cs[q][j];
+                    x += dpp_move<0xB1>(x);
+                    x += dpp_move<0x4E>(x);
+                    x += dpp_move<0x141>(x);
+                    x += dpp_move<0x140>(x);
+                    cs[q][j] = x;
+                }
+            if (l15 == 0) {
+#pragma unroll
+                for (int q = 0; q < 2; ++q)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) red[wm * TN + 64 * wn + 32 * q + 8 * kg + j] = cs[q][j];
+            }
+            __syncthreads();
+            const float tot = tid < TN ? red[tid] + red[TN + tid] : 0.f;
+            const __amdgpu_buffer_rsrc_t prs =
+                make_rsrc(ffn.part ? ffn.part + (m0 / TM) * (long)N + n0 : nullptr, ffn.part ? (uint32_t)(ncols * 4) : 0u);
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, tot), prs, tid < TN ? tid * 4 : 0x7ffffff0, 0, 0);
+            __syncthreads();                                   // the strip is free for the next tile's sums
+        }
+        }
         __builtin_amdgcn_sched_barrier(0);
         GB_STAMP()
         if (!has_next) break;
@@ -451,6 +561,86 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 
 static int g_variant = -1;      // -1: default; see cwlt_gemm_bf16_tune
 static uint32_t* g_trace = nullptr;
+
+namespace cwlt {
+
+// epi: 0..3 (bias | accumulate << 1), gb::EPI_GELU, gb::EPI_MUL.  Arguments checked by the callers.
+static int launch_gemm_big(int epi, const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K,
+                           int64_t lda, int64_t ldw, int64_t ldc, gb::FfnArgs ffn, hipStream_t stream) {
+    const long mtiles = (M + gb::TM - 1) / gb::TM;
+    const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
+    const long nblk = mt8 * ((N + gb::TN - 1) / gb::TN);
+    if (nblk >= (1ll << 30)) return CWLT_ERR_ARG;
+    // one workgroup per CU (128 KiB of LDS, 256 registers x 8 waves), in multiples of 8 so that a workgroup's tiles
+    // stay on its XCD's share of the tile order
+    static int ncu[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (!ncu[dev]) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        ncu[dev] = n / 8 * 8;
+    }
+    long grid = nblk < ncu[dev] ? nblk : ncu[dev];
+    const int var = g_variant < 0 ? 0 : g_variant;
+    const int glim = ((var >> 8) & 255) * 8;
+    if (glim && glim < grid) grid = glim;
+    // Start stagger, in units of 64 cycles per group step (16 groups; a tile period is ~3 500 cycles per K-tile +
+    // ~14 000).  Default: half a tile period for K <= 1024 (there a tile's 128 KiB of stores + the next tile's first
+    // operands are a third of its time, and with every workgroup at the same point the chip alternates between
+    // saturating HBM and leaving it idle: 336 -> 300 us at K = N = 512, R = 524 288), none above (a K = 2048 tile is
+    // 55 us of main loop: 905 us with or without, and the stagger costs its own length once per launch).
+    const int stag8 = g_variant < 0 ? (K <= 1024 ? 4 : 0) : ((var >> 1) & 7);
+    const int stagger = (int)(stag8 * ((K / gb::BK) * 3500L + 14000L) / (8 * 16 * 64));
+    const int abl = (var >> 4) & 15;
+    typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long, int,
+                          uint32_t*, int, gb::FfnArgs);
+    kfn_t kfn = nullptr;
+    uint32_t* tr = (epi == 0) ? g_trace : nullptr;
+    const bool late = var & 1;
+    switch (epi) {
+        case 0:
+            kfn = tr ? (late ? gb::gemm_bf16_kernel<0, true, 0, false> : gb::gemm_bf16_kernel<0, true, 0, true>)
+                     : (late ? gb::gemm_bf16_kernel<0, false, 0, false> : gb::gemm_bf16_kernel<0, false, 0, true>);
+            break;
+        case 1: kfn = late ? gb::gemm_bf16_kernel<1, false, 0, false> : gb::gemm_bf16_kernel<1, false, 0, true>; break;
+        case 2: kfn = late ? gb::gemm_bf16_kernel<2, false, 0, false> : gb::gemm_bf16_kernel<2, false, 0, true>; break;
+        case 3: kfn = late ? gb::gemm_bf16_kernel<3, false, 0, false> : gb::gemm_bf16_kernel<3, false, 0, true>; break;
+        case gb::EPI_GELU: kfn = gb::gemm_bf16_kernel<gb::EPI_GELU, false, 0, true>; break;
+        case gb::EPI_MUL: kfn = gb::gemm_bf16_kernel<gb::EPI_MUL, false, 0, true>; break;
+        default: return CWLT_ERR_ARG;
+    }
+    if (epi == 0 && !tr && abl) {
+        switch (abl) {
+            case 1: kfn = gb::gemm_bf16_kernel<0, false, 1>; break;
+            case 2: kfn = gb::gemm_bf16_kernel<0, false, 2>; break;
+            case 3: kfn = gb::gemm_bf16_kernel<0, false, 3>; break;
+            case 4: kfn = gb::gemm_bf16_kernel<0, false, 4>; break;
+            case 5: kfn = gb::gemm_bf16_kernel<0, false, 5>; break;
+            case 6: kfn = gb::gemm_bf16_kernel<0, false, 6>; break;
+            case 7: kfn = gb::gemm_bf16_kernel<0, false, 7>; break;
+            default: kfn = gb::gemm_bf16_kernel<0, false, 8>; break;
+        }
+    }
+    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), 0, stream, (const bf16_t*)a, (const bf16_t*)w, bias,
+                       (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc, (int)nblk, tr, stagger, ffn);
+    return (int)hipGetLastError();
+}
+
+// FFN forms on the 256 x 256 persistent kernel (called from gemm_nt.hip's entry points, which have checked the
+// arguments): gelu != 0: g = c (written), gd = G (written), bias, dropout (thresh, keep_scale, seed, seed_base);
+// gelu == 0: c = (a w^T) * G, part = column-sum partials of c per 256-row tile (or NULL).
+int launch_gemm_ffn_big(int gelu, const void* a, const void* w, const float* bias, void* g, void* c, float* part,
+                        int64_t M, int N, int K, int64_t lda, int64_t ldw, uint32_t thresh, float keep_scale,
+                        uint64_t seed, const uint64_t* seed_base, hipStream_t st) {
+    if (K < 128 || (K % 64) || (N % 8) || N > gb::MAXN_BIAS) return CWLT_ERR_ARG;
+    if ((int64_t)gb::TM * N * 2 >= (1ll << 30)) return CWLT_ERR_ARG;
+    gb::FfnArgs ffn{(bf16_t*)g, part, thresh, keep_scale, seed, seed_base};
+    return launch_gemm_big(gelu ? gb::EPI_GELU : gb::EPI_MUL, a, w, bias, c, M, N, K, lda, ldw, N, ffn, st);
+}
+long gemm_ffn_big_tiles(long M) { return (M + gb::TM - 1) / gb::TM; }
+
+}  // namespace cwlt
 
 extern "C" {
 
@@ -483,62 +673,8 @@ int cwlt_gemm_bf16(const void* a, const void* w, const float* bias, void* c, int
     if ((int64_t)gb::TM * lda * 2 >= (1ll << 31) || (int64_t)gb::TN * ldw * 2 >= (1ll << 31) ||
         (int64_t)gb::TM * ldc * 2 >= (1ll << 30))
         return CWLT_ERR_ARG;
-    const long mtiles = (M + gb::TM - 1) / gb::TM;
-    const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
-    const long nblk = mt8 * ((N + gb::TN - 1) / gb::TN);
-    if (nblk >= (1ll << 30)) return CWLT_ERR_ARG;
-    // one workgroup per CU (128 KiB of LDS, 256 registers x 8 waves), in multiples of 8 so that a workgroup's tiles
-    // stay on its XCD's share of the tile order
-    static int ncu[64];
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
-    if (!ncu[dev]) {
-        int n = 0;
-        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
-        ncu[dev] = n / 8 * 8;
-    }
-    long grid = nblk < ncu[dev] ? nblk : ncu[dev];
     const int epi = (bias ? 1 : 0) | (accumulate ? 2 : 0);
-    const int var = g_variant < 0 ? 0 : g_variant;
-    const int glim = ((var >> 8) & 255) * 8;
-    if (glim && glim < grid) grid = glim;
-    // Start stagger, in units of 64 cycles per group step (16 groups; a tile period is ~3 500 cycles per K-tile +
-    // ~14 000).  Default: half a tile period for K <= 1024 (there a tile's 128 KiB of stores + the next tile's first
-    // operands are a third of its time, and with every workgroup at the same point the chip alternates between
-    // saturating HBM and leaving it idle: 336 -> 300 us at K = N = 512, R = 524 288), none above (a K = 2048 tile is
-    // 55 us of main loop: 905 us with or without, and the stagger costs its own length once per launch).
-    const int stag8 = g_variant < 0 ? (K <= 1024 ? 4 : 0) : ((var >> 1) & 7);
-    const int stagger = (int)(stag8 * ((K / gb::BK) * 3500L + 14000L) / (8 * 16 * 64));
-    const int abl = (var >> 4) & 15;
-    typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long, int,
-                          uint32_t*, int);
-    kfn_t kfn = nullptr;
-    uint32_t* tr = (epi == 0) ? g_trace : nullptr;
-    const bool late = var & 1;
-    switch (epi) {
-        case 0:
-            kfn = tr ? (late ? gb::gemm_bf16_kernel<0, true, 0, false> : gb::gemm_bf16_kernel<0, true, 0, true>)
-                     : (late ? gb::gemm_bf16_kernel<0, false, 0, false> : gb::gemm_bf16_kernel<0, false, 0, true>);
-            break;
-        case 1: kfn = late ? gb::gemm_bf16_kernel<1, false, 0, false> : gb::gemm_bf16_kernel<1, false, 0, true>; break;
-        case 2: kfn = late ? gb::gemm_bf16_kernel<2, false, 0, false> : gb::gemm_bf16_kernel<2, false, 0, true>; break;
-        default: kfn = late ? gb::gemm_bf16_kernel<3, false, 0, false> : gb::gemm_bf16_kernel<3, false, 0, true>; break;
-    }
-    if (epi == 0 && !tr && abl) {
-        switch (abl) {
-            case 1: kfn = gb::gemm_bf16_kernel<0, false, 1>; break;
-            case 2: kfn = gb::gemm_bf16_kernel<0, false, 2>; break;
-            case 3: kfn = gb::gemm_bf16_kernel<0, false, 3>; break;
-            case 4: kfn = gb::gemm_bf16_kernel<0, false, 4>; break;
-            case 5: kfn = gb::gemm_bf16_kernel<0, false, 5>; break;
-            case 6: kfn = gb::gemm_bf16_kernel<0, false, 6>; break;
-            case 7: kfn = gb::gemm_bf16_kernel<0, false, 7>; break;
-            default: kfn = gb::gemm_bf16_kernel<0, false, 8>; break;
-        }
-    }
-    hipLaunchKernelGGL(kfn, dim3((unsigned)grid), dim3(512), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w,
-                       bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw, (long)ldc, (int)nblk, tr, stagger);
-    return (int)hipGetLastError();
+    return launch_gemm_big(epi, a, w, bias, c, M, N, K, lda, ldw, ldc, gb::FfnArgs{}, (hipStream_t)stream);
 }
 
 }  // extern "C"

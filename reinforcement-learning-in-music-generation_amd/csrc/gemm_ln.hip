@@ -134,7 +134,7 @@ __global__ __launch_bounds__(1024) void gemm_ln_kernel(
     // so every MFMA group finds its operands in registers, and the LDS reads, the DMA issue and the barrier wait of a
     // wave fall under MFMAs already queued.  Worth 1-3 % here (0.597 -> 0.589 ms at K = 512): the step is not paced by
     // fragment latency but by the operand pieces themselves -- 40 KiB per step from L2 through the CU's one
-    // vector-memory queue, ~1 us per step against 0.49 us of MFMA work; issuing the pieces after the
+    // vector-memory queue, ~1 us per step against 0.49 us of MFMA work (HISTORY 4.2c); issuing the pieces after the
     // second MFMA group instead of behind the barrier is slower (0.62 ms).
     // A wave leaves its OWN pieces of the youngest step in flight at the wait: 3 for waves 0-7, 2 for waves 8-15.
     const int nstep = K / BK;                         // K is a multiple of 64 (launcher): nstep >= 2

@@ -277,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void gemm_nt_mul_kernel(
         // output addresses (+ 16 rows), the dropout key's pair index (+ 16 N / 2) and its first multiply
         // ((lo + d) C = lo C + d C, exact mod 2^32) -- the row loop held a 64-bit multiply and three 32-bit ones per row
         // for them, in a kernel whose epilogue instructions cost the neighbouring workgroup's main loop their time
-        // (DESIGN 4.2c).
+        // (HISTORY 4.2c).
         // element index of (row, column) in the dense (M, N) activation: what cwlt_bias_gelu_dropout_fwd keys its mask
         // with (the launcher insists on ldc == ldg == N).  The keep flags of dropout_mask<8>(seed, off, thresh), bit for
         // bit: the four pair indices (off >> 1) + 0..3 share their upper word and key (off is a multiple of 8, so the low
@@ -441,6 +441,13 @@ static int interleave_dma() {   // CWLT_GEMM_NT_ILV=0: all of a step's pieces is
     static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_ILV"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
 }
+// CWLT_FFN_BIG=0: always the 128 x 256 two-workgroups-per-CU kernel below (A/B switch).  Default: from 32 768 rows on the
+// FFN forms run on gemm_bf16.hip's 256 x 256 persistent kernel (one workgroup per CU needs many row tiles to fill the chip).
+static bool ffn_big(int64_t M, int N, int K) {
+    static const int v = [] { const char* e = getenv("CWLT_FFN_BIG"); return (e && e[0] == '0') ? 0 : 1; }();
+    static const long min_rows = [] { const char* e = getenv("CWLT_FFN_BIG_MIN_ROWS"); return e ? atol(e) : 32768L; }();
+    return v && M >= min_rows && K >= 128 && N <= 8192;
+}
 static int spread_starts() {   // CWLT_GEMM_NT_SPREAD=0: all workgroups start at once (A/B switch)
     static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_SPREAD"); return (e && e[0] == '0') ? 0 : 1; }();
     return v;
@@ -468,6 +475,13 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
     /* byte offsets inside one row tile / one weight strip are 32-bit (buffer resources); tile bases are 64-bit */
     if ((int64_t)gn::TMR * (lda > ldg ? lda : ldg) * 2 >= (1ll << 31) || (int64_t)gn::TNC * ldw * 2 >= (1ll << 31))
         return CWLT_ERR_ARG;
+    if (ffn_big(M, N, K) && ldg == N && ldc == N) {
+        // training sizes: the 256 x 256 persistent kernel of gemm_bf16.hip with this epilogue (same arithmetic; the column
+        // sums come per 256-row tile)
+        int e = launch_gemm_ffn_big(0, a, w, nullptr, const_cast<void*>(g), c, part, M, N, K, lda, ldw, 0u, 1.0f, 0, nullptr, st);
+        if (e || !colsum) return e;
+        return launch_colsum_finalize(part, colsum, (int)gemm_ffn_big_tiles(M), (long)N, N, 1.0f, 0, st);
+    }
     const long mtiles = (M + gn::TMR - 1) / gn::TMR;
     const long mt8 = (mtiles + 7) / 8 * 8;            // row tiles are dealt to the 8 XCDs: pad to a multiple of 8
     const long nblk = mt8 * (N / gn::TNC);
@@ -500,6 +514,9 @@ int cwlt_gemm_nt_bias_gelu_dropout(const void* a, const void* w, const float* bi
     if (((lda | ldw) & 7) || lda < K || ldw < K) return CWLT_ERR_ARG;
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)g | (uintptr_t)gd | (uintptr_t)bias) & 15) return CWLT_ERR_ARG;
     if ((int64_t)gn::TMR * lda * 2 >= (1ll << 31) || (int64_t)gn::TNC * ldw * 2 >= (1ll << 31)) return CWLT_ERR_ARG;
+    if (ffn_big(M, N, K))
+        return launch_gemm_ffn_big(1, a, w, bias, gd, g, nullptr, M, N, K, lda, ldw, drop_thresh(p), drop_scale(p), seed,
+                                   seed_base, (hipStream_t)stream);
     const long mtiles = (M + gn::TMR - 1) / gn::TMR;
     const long mt8 = (mtiles + 7) / 8 * 8;
     const long nblk = mt8 * (N / gn::TNC);

@@ -1,5 +1,5 @@
 // How fast can ONE compute unit push stores to HBM, and what do a co-resident workgroup's L2-hit loads get meanwhile?
-// (The question behind DESIGN 4.2c: the one-kernel FFN forward is main loop + store drain, nothing overlaps.)
+// (The question behind HISTORY 4.2c: the one-kernel FFN forward is main loop + store drain, nothing overlaps.)
 //   store-only:  W workgroups (256 threads) each write `tiles` tiles of 128 rows x 512 bytes (row stride 4 096 B: the FFN
 //                forward's output tile), 16 bytes per lane; W = 8 ... 512 -> GB/s in total and per workgroup (= per CU while
 //                W <= 256: workgroups are dealt round-robin over the XCDs and their CUs).

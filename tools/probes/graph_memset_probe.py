@@ -1,6 +1,6 @@
 """Does a zero-fill captured into a hipGraph still write zeros when the graph is replayed with other work in between?
 
-DESIGN 4.4 recorded (decode experiments, round 1): "a hipMemsetAsync captured into a hipGraph replayed with a garbage
+HISTORY 4.4 recorded (decode experiments, round 1): "a hipMemsetAsync captured into a hipGraph replayed with a garbage
 fill pattern (ROCm 7.2)".  A captured training step contains exactly such fills -- `GradSync.zero_grad()`
 (`flat.zero_()` on 32 MiB buckets) and `torch.zeros` of the TD-loss gradient -- and round 1's unexplained fault (NaN
 losses from the third replay on, once an illegal address, only with LARGE EAGER GEMMs between replays) is what a fill

@@ -1,5 +1,5 @@
 // L2 -> LDS DMA (buffer_load_dwordx4 ... lds) throughput of one CU from an L2-resident buffer, against the number of waves
-// issuing and the number of 1 KiB pieces each keeps in flight.  The question behind DESIGN 9.7(e): the FFN kernels and
+// issuing and the number of 1 KiB pieces each keeps in flight.  The question behind HISTORY 9.7(e): the FFN kernels and
 // gemm_ln.hip both take in 40-43 GB/s of operand pieces per CU -- latency x depth, or the path's throughput?
 //   hipcc --offload-arch=gfx950 -O3 -o ldsdma_rate tools/probes/ldsdma_rate.hip && ./ldsdma_rate
 #include <hip/hip_runtime.h>

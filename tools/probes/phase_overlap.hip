@@ -1,4 +1,4 @@
-// A model of a GEMM whose tiles end in a store burst: 512 workgroups of 256 threads, two per CU; each does
+// A model of a GEMM whose tiles end in a store burst (HISTORY 4.2c): 512 workgroups of 256 threads, two per CU; each does
 // `tiles` times  [ M: read 16 x 24 KiB of an L2-resident slab, the operand pieces of a 16-step main loop | S: store one
 // 128-row x 512-byte tile of each of two outputs = 128 KiB ].  Times: M only, S only, M + S with all workgroups starting
 // together, M + S with the first two workgroups of every CU started 0..7 x ~4 us apart.  If the last is close to
