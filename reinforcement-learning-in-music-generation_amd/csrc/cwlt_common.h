@@ -225,6 +225,10 @@ int launch_gemm_ffn_big(int gelu, const void* a, const void* w, const float* bia
                         uint64_t seed, const uint64_t* seed_base, hipStream_t st);
 long gemm_ffn_big_tiles(long M);
 
+// wgrad2.hip: the weight-gradient GEMM on gemm_bf16.hip's main loop (N1, N2 multiples of 256; mslice a multiple of 64, >= 256)
+int launch_wgrad2(const void* a, const void* b, float* part, long M, int N1, int N2, long lda, long ldb, long mslice, int S,
+                  hipStream_t st);
+
 // bf16 throughput path of the causal linear attention (cla_bf16.hip); row strides must be multiples of 8.
 // P = segments per stream (scan_segments: 1 unless N * H is far below the CU count), ws = scan_seg_floats(...) floats.
 int scan_segments(int N, int H, int L);

@@ -291,10 +291,12 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
 
     // Every workgroup takes the same time per tile, so left alone the whole chip stores its 256 x 128 KiB of output and
     // requests the next tiles' first operands in the same few microseconds and then leaves HBM idle for a main loop.
-    // Workgroups start `stagger` x 64 cycles apart in 16 groups (spread over a fraction of a tile period), after which
-    // the bursts of different CUs fall into each other's main loops.
+    // Workgroups start `stagger` x 64 cycles apart, one group per ROW tile of an XCD's share (spread over a fraction of
+    // a tile period), after which the bursts of different CUs fall into each other's main loops.  The column tiles of a
+    // row tile stay together: they read the same A strip, and apart in time each of them would fetch it from HBM again
+    // (counter traffic of the N = 2048 forms: 1.25 x algorithmic with the groups dealt by workgroup id).
     if (stagger) {
-        for (int left = ((blockIdx.x >> 3) & 15) * stagger; left > 0; left -= 64) __builtin_amdgcn_s_sleep(64);
+        for (int left = (int)((blockIdx.x >> 3) / nt) * stagger; left > 0; left -= 64) __builtin_amdgcn_s_sleep(64);
     }
     GB_NEXT((int)blockIdx.x - (int)gridDim.x, idx)
     if (idx >= nblk) return;
@@ -585,13 +587,15 @@ static int launch_gemm_big(int epi, const void* a, const void* w, const float* b
     const int var = g_variant < 0 ? 0 : g_variant;
     const int glim = ((var >> 8) & 255) * 8;
     if (glim && glim < grid) grid = glim;
-    // Start stagger, in units of 64 cycles per group step (16 groups; a tile period is ~3 500 cycles per K-tile +
-    // ~14 000).  Default: half a tile period for K <= 1024 (there a tile's 128 KiB of stores + the next tile's first
+    // Start stagger, in units of 64 cycles per group step (one group per row tile an XCD holds at a time; a tile period
+    // is ~3 500 cycles per K-tile + ~14 000).  Default: half a tile period for K <= 1024 (there a tile's 128 KiB of stores + the next tile's first
     // operands are a third of its time, and with every workgroup at the same point the chip alternates between
     // saturating HBM and leaving it idle: 336 -> 300 us at K = N = 512, R = 524 288), none above (a K = 2048 tile is
     // 55 us of main loop: 905 us with or without, and the stagger costs its own length once per launch).
     const int stag8 = g_variant < 0 ? (K <= 1024 ? 4 : 0) : ((var >> 1) & 7);
-    const int stagger = (int)(stag8 * ((K / gb::BK) * 3500L + 14000L) / (8 * 16 * 64));
+    const long ntc = (N + gb::TN - 1) / gb::TN;
+    const long ngroup = (grid / 8 + ntc - 1) / ntc > 0 ? (grid / 8 + ntc - 1) / ntc : 1;     // row tiles an XCD holds at a time
+    const int stagger = (int)(stag8 * ((K / gb::BK) * 3500L + 14000L) / (8 * ngroup * 64));
     const int abl = (var >> 4) & 15;
     typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long, int,
                           uint32_t*, int, gb::FfnArgs);

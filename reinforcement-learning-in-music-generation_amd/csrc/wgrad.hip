@@ -14,6 +14,7 @@
 //     an f32 partial tile and a fixed-order reduce kernel sums them straight into the f32 gradient
 //     buffer (deterministic, no atomics, no bf16 rounding of the gradient).
 #include "cwlt_common.h"
+#include <stdlib.h>
 
 namespace cwlt {
 namespace wg {
@@ -298,6 +299,22 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
     long mslice = (M + S - 1) / S;
     mslice = (mslice + wg::BK - 1) / wg::BK * wg::BK;                   // whole 32-row steps
     hipStream_t st = (hipStream_t)stream;
+    // CWLT_WGRAD_V2=1 (both widths multiples of 256, slices of at least 4 K-tiles): the 8-wave form on gemm_bf16.hip's main
+    // loop (wgrad2.hip).  Measured equal to this file's 16-wave kernel -- 945-958 / 918-924 / 284-287 / 807-811 us against
+    // 970-985 / 919-922 / 288-292 / 803-806 on the four layer shapes at R = 524 288 (profiles/r04_wgrad2.txt): both run at
+    // the 1.15-1.2 PFLOP/s the chip holds under this load (1.68 GHz), so it stays a switch.
+    static const bool v2 = [] { const char* e = getenv("CWLT_WGRAD_V2"); return e && e[0] == '1'; }();
+    if (v2 && !(N1 & 255) && !(N2 & 255)) {
+        const long ms2 = (mslice + 63) / 64 * 64;
+        if (ms2 >= 256 && (int64_t)ms2 * (lda > ldb ? lda : ldb) * 2 < (1ll << 31)) {
+            int e = launch_wgrad2(a, b, part, (long)M, N1, N2, (long)lda, (long)ldb, ms2, S, st);
+            if (e) return e;
+            const long n = (long)N1 * N2;
+            hipLaunchKernelGGL(wg::wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, part, out,
+                               S, n, accumulate);
+            return (int)hipGetLastError();
+        }
+    }
     const bool edge = (N1 & 255) || (N2 & 255);
     constexpr int lds_bytes = wg::NSTAGE * 2 * wg::OPB;                 // 128 KiB: above the 64 KiB default limit
     // the opt-in is per device: remember which devices have it (a process may launch on several)

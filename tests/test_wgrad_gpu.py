@@ -44,3 +44,38 @@ def test_wgrad_edge_tile_on_column_slices(cuda):
     ref = a.double().t() @ b.double()
     assert got.shape == (384, 1216)
     assert (got.double() - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
+def test_wgrad2_switch_matches_fp64_in_a_process_of_its_own(cuda):
+    """CWLT_WGRAD_V2=1 (read once per process): the 8-wave form on gemm_bf16.hip's main loop (csrc/wgrad2.hip) against the
+    f64 reference -- ragged token counts (slices ending inside a K-tile), strided operands (column blocks of a wider
+    tensor), accumulate, and bit-for-bit determinism."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+import torch
+import rlmg_amd
+from rlmg_amd import ops
+dev = torch.device("cuda:0")
+for M, N1, N2 in ((70000, 512, 512), (33333, 2048, 512), (40000, 512, 1536), (2048, 256, 256)):
+    g = torch.Generator().manual_seed(M)
+    wide = torch.randn(M, N1 + 256, generator=g).bfloat16().to(dev)
+    a = wide[:, 128:128 + N1]                       # row stride N1 + 256, 16-byte aligned start
+    b = torch.randn(M, N2, generator=g).bfloat16().to(dev)
+    ref = a.double().t() @ b.double()
+    got = ops.wgrad(a, b)
+    assert torch.equal(got, ops.wgrad(a, b))
+    scale = max(1.0, ref.abs().max().item())
+    assert (got.double() - ref).abs().max().item() <= 1e-4 * scale, (M, N1, N2)
+    acc = torch.ones(N1, N2, device=dev)
+    ops.wgrad(a, b, out=acc, accumulate=True)
+    assert (acc.double() - (ref + 1)).abs().max().item() <= 1e-4 * scale, (M, N1, N2)
+print("wgrad2 ok")
+''' % root
+    env = dict(os.environ, CWLT_WGRAD_V2="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "wgrad2 ok" in r.stdout, r.stdout + r.stderr

@@ -21,7 +21,10 @@ ENTRY = [("cla_fwd_bf16_kernel", "cwlt_causal_linear_fwd"), ("cla_bwd_sweep_bf16
          ("wgrad_reduce_kernel", "cwlt_wgrad_bf16"), ("cw_embed_proj_bwd", "cwlt_cw_embed_proj_bwd"),
          ("cw_embed_proj_fwd", "cwlt_cw_embed_proj_fwd"), ("cw_embed_bwd", "cwlt_cw_embed_bwd"), ("cw_embed_fwd", "cwlt_cw_embed_fwd"),
          ("heads_fwd", "cwlt_heads_fwd"), ("heads_ce_bwd", "cwlt_heads_ce_bwd"), ("posenc_dropout_kernel", "cwlt_posenc_dropout"),
-         ("gemm_ln_kernel", "cwlt_gemm_nt_bias_dropout_add_layernorm"), ("gemm_nt_mul_kernel<1", "cwlt_gemm_nt_bias_gelu_dropout"), ("gemm_nt_mul_kernel", "cwlt_gemm_nt_mul")]
+         ("gemm_ln_kernel", "cwlt_gemm_nt_bias_dropout_add_layernorm"), ("gemm_nt_mul_kernel<1", "cwlt_gemm_nt_bias_gelu_dropout"), ("gemm_nt_mul_kernel", "cwlt_gemm_nt_mul"),
+         # gemm_bf16.hip's persistent kernel: EPI 4 / 8 are the FFN forms, 0..3 the plain projections (averaged over their shapes)
+         ("gemm_bf16_kernel<4", "cwlt_gemm_nt_bias_gelu_dropout"), ("gemm_bf16_kernel<8", "cwlt_gemm_nt_mul"),
+         ("gemm_bf16_kernel", "cwlt_gemm_bf16")]
 MAIN = {"cwlt_wgrad_bf16": "wgrad_kernel"}      # launches counted by the main kernel of multi-kernel entry points
 
 
