@@ -443,10 +443,14 @@ static int interleave_dma() {   // CWLT_GEMM_NT_ILV=0: all of a step's pieces is
 }
 // CWLT_FFN_BIG=0: always the 128 x 256 two-workgroups-per-CU kernel below (A/B switch).  Default: from 32 768 rows on the
 // FFN forms run on gemm_bf16.hip's 256 x 256 persistent kernel (one workgroup per CU needs many row tiles to fill the chip).
-static bool ffn_big(int64_t M, int N, int K) {
-    static const int v = [] { const char* e = getenv("CWLT_FFN_BIG"); return (e && e[0] == '0') ? 0 : 1; }();
+// (CWLT_FFN_BIG=f / b: only the forward / only the backward form.)
+static bool ffn_big(int64_t M, int N, int K, bool fwd = true) {
+    static const int v = [] {
+        const char* e = getenv("CWLT_FFN_BIG");
+        return !e ? 3 : e[0] == '0' ? 0 : e[0] == 'f' ? 1 : e[0] == 'b' ? 2 : 3;
+    }();
     static const long min_rows = [] { const char* e = getenv("CWLT_FFN_BIG_MIN_ROWS"); return e ? atol(e) : 32768L; }();
-    return v && M >= min_rows && K >= 128 && N <= 8192;
+    return (v & (fwd ? 1 : 2)) && M >= min_rows && K >= 128 && N <= 8192;
 }
 static int spread_starts() {   // CWLT_GEMM_NT_SPREAD=0: all workgroups start at once (A/B switch)
     static const int v = [] { const char* e = getenv("CWLT_GEMM_NT_SPREAD"); return (e && e[0] == '0') ? 0 : 1; }();
@@ -475,7 +479,7 @@ int cwlt_gemm_nt_mul(const void* a, const void* w, const void* g, void* c, float
     /* byte offsets inside one row tile / one weight strip are 32-bit (buffer resources); tile bases are 64-bit */
     if ((int64_t)gn::TMR * (lda > ldg ? lda : ldg) * 2 >= (1ll << 31) || (int64_t)gn::TNC * ldw * 2 >= (1ll << 31))
         return CWLT_ERR_ARG;
-    if (ffn_big(M, N, K) && ldg == N && ldc == N) {
+    if (ffn_big(M, N, K, false) && ldg == N && ldc == N) {
         // training sizes: the 256 x 256 persistent kernel of gemm_bf16.hip with this epilogue (same arithmetic; the column
         // sums come per 256-row tile)
         int e = launch_gemm_ffn_big(0, a, w, nullptr, const_cast<void*>(g), c, part, M, N, K, lda, ldw, 0u, 1.0f, 0, nullptr, st);

@@ -56,9 +56,12 @@ class _EncoderLayerFn(torch.autograd.Function):
         R = N * L
         adt = x.dtype
         x2 = x.reshape(R, D)
+        bqkv32 = None
         if shadow is not None:
-            # compute-dtype copies kept (and refreshed with one multi-tensor copy) by the encoder: ops.ShadowSet
-            wqkv, bqkv, wo_a, bo_a, w1_a, w2_a, b2_a = shadow
+            # compute-dtype copies kept (and refreshed with one multi-tensor copy) by the encoder: ops.ShadowSet;
+            # an 8th entry is the stacked Q/K/V bias in f32 (what cwlt_gemm_bf16 adds before its one rounding)
+            wqkv, bqkv, wo_a, bo_a, w1_a, w2_a, b2_a = shadow[:7]
+            bqkv32 = shadow[7] if len(shadow) > 7 else None
         else:
             wqkv = torch.cat([wq, wk, wv], 0).to(adt)
             bqkv = torch.cat([bq, bk, bv], 0).to(adt)
@@ -67,7 +70,9 @@ class _EncoderLayerFn(torch.autograd.Function):
         g1f, be1f, g2f, be2f, b1f = (ops._f32(t) for t in (g1, be1, g2, be2, b1))
 
         if ops.gemm_bf16_supported(x2, wqkv):
-            qkv = ops.gemm_bf16(x2, wqkv, torch.cat([ops._f32(bq), ops._f32(bk), ops._f32(bv)]))   # (R, 3D)  MFMA
+            if bqkv32 is None:
+                bqkv32 = torch.cat([ops._f32(bq), ops._f32(bk), ops._f32(bv)])
+            qkv = ops.gemm_bf16(x2, wqkv, bqkv32)                          # (R, 3D)  MFMA
         else:
             qkv = torch.addmm(bqkv, x2, wqkv.t())
         qkv5 = qkv.view(N, L, 3, H, D // H)
@@ -251,6 +256,7 @@ class TransformerEncoder(nn.Module):
         self.layers = nn.ModuleList(layers)
         self.norm = norm_layer
         self._shadow = None                                  # ops.ShadowSet of the layers' compute-dtype weights
+        self._shadow32 = None                                # ... and of the stacked Q/K/V biases in f32 (bf16 mode)
 
     def forward(self, x, attn_mask=None, length_mask=None):
         if length_mask is not None:
@@ -262,8 +268,15 @@ class TransformerEncoder(nn.Module):
         if sh is None or not sh.matches(x.dtype, x.device):
             sh = self._shadow = ops.ShadowSet([g for layer in self.layers for g in layer.shadow_groups()], x.dtype)
         bufs = sh.refresh()
+        bufs32 = None
+        if x.dtype == torch.bfloat16 and x.shape[0] * x.shape[1] >= ops.GEMM_BF16_MIN_ROWS and ops.GEMM_BF16:
+            s32 = self._shadow32
+            if s32 is None or not s32.matches(torch.float32, x.device):
+                s32 = self._shadow32 = ops.ShadowSet([layer.shadow_groups()[1] for layer in self.layers], torch.float32)
+            bufs32 = s32.refresh()
         for i, layer in enumerate(self.layers):
-            x = layer(x, attn_mask, tuple(bufs[per * i:per * (i + 1)]))
+            sh_i = tuple(bufs[per * i:per * (i + 1)])
+            x = layer(x, attn_mask, sh_i + (bufs32[i],) if bufs32 is not None else sh_i)
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x
