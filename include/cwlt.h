@@ -411,6 +411,73 @@ int cwlt_sample_categorical(const float* logits, const int* n_class, const float
                             const int64_t* counter, int64_t* tokens, int64_t* song, int64_t song_rows,
                             void* stream);
 
+/* ---- the dense projections at few token rows, and a whole encoder layer per host call ---------------------------------
+ * The reference's own RL setting is 30 windows x 50 tokens = 1 500 token rows per network pass
+ * (dqn_policy/IRL_dqn_train.py:267-345 `DQN.update`, ppo_policy/ppo_train.py:365-417 `update_policy`): ~970 launches of
+ * ~10 us per update, bound by the HOST when every launch is its own Python-level call.
+ *
+ * cwlt_gemm_bf16_small: cwlt_gemm_bf16's product on 64 x 64 output tiles (192-768 workgroups at 1 500 rows where 256-row
+ * tiles leave 12), operands straight from L2 into MFMA fragments.  N % 8 == 0, K % 32 == 0, row strides multiples of 8,
+ * 16-byte aligned pointers; same arithmetic (f32 accumulation, bias in f32, one rounding).
+ * cwlt_transpose_bf16_many: dst_i (cols, rows) = src_i (rows, cols)^T for the n dense bf16 matrices of `table` (DEVICE
+ * memory, n x 4 int64: element offset from src, element offset from dst, rows, cols) in one launch -- the transposed
+ * weight copies the input-gradient products read. */
+int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int64_t lda,
+                         int64_t ldw, int64_t ldc, int accumulate, void* stream);
+int cwlt_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, void* stream);
+
+/* One post-LN encoder layer -- fast_transformers' TransformerEncoderLayer(AttentionLayer(CausalLinearAttention)) as
+ * built at dqn_policy/model.py:128-137 (ppo_policy/model.py:129-138) and called at :232:
+ *     x1 = norm1(x + dropout(out_projection(causal_linear_attention(q, k, v))));
+ *     y  = norm2(x1 + dropout(linear2(dropout(gelu(linear1(x1))))))
+ * -- enqueued by ONE host call forward (8 launches) and one backward (19-21 launches), through the entry points above
+ * (same kernels, same dropout streams as the per-op path).  bf16 activations; d_model 512, 8 heads of 64, d_ff % 256 == 0.
+ * The struct is HOST memory, read during the call only; every pointer in it is a device pointer.
+ * forward : reads x and the parameters; writes y and `saved`; uses `scratch` (fwd_scratch_bytes).
+ * backward: reads dy, x, `saved` (of the matching forward, same n_seq/len/p_drop/seeds/want_backward = 1), the
+ *           TRANSPOSED weight copies and gamma1/gamma2; writes dx and `grads`; uses `scratch` (bwd_scratch_bytes).
+ * All buffers 256-byte aligned.  grads (f32, grad_floats): the 12 parameter gradients at grad_off[] (float offsets),
+ * in the order CWLT_LAYER_GRAD_* below; the Q / K / V weight (bias) gradients are the three row blocks of wqkv (bqkv). */
+#define CWLT_LAYER_NGRADS 12
+#define CWLT_LAYER_NSAVED 13
+enum { CWLT_LAYER_GRAD_WQKV = 0, CWLT_LAYER_GRAD_BQKV, CWLT_LAYER_GRAD_WO, CWLT_LAYER_GRAD_BO, CWLT_LAYER_GRAD_W1,
+       CWLT_LAYER_GRAD_B1, CWLT_LAYER_GRAD_W2, CWLT_LAYER_GRAD_B2, CWLT_LAYER_GRAD_GAMMA1, CWLT_LAYER_GRAD_BETA1,
+       CWLT_LAYER_GRAD_GAMMA2, CWLT_LAYER_GRAD_BETA2 };
+typedef struct cwlt_encoder_layer {
+    int64_t n_seq, len;                /* N sequences x L tokens: R = N L token rows */
+    int32_t d_model, d_ff, n_heads;
+    int32_t want_backward;             /* forward: also leave the scan's final state for a one-sweep backward */
+    float p_drop, ln_eps, attn_eps;    /* dropout probability (0 in eval mode); 1e-5, 1e-6 in the reference */
+    int32_t reserved;
+    uint64_t seed[3];                  /* dropout streams: residual block 1, FFN, residual block 2 */
+    const uint64_t* seed_base;         /* optional device uint64 added to every seed (hipGraph replays), or NULL */
+    const void *wqkv, *wo, *w1, *w2;   /* bf16 (3D, D) query|key|value rows stacked, (D, D), (F, D), (D, F) as stored */
+    const float *bqkv, *bo, *b1, *b2, *gamma1, *beta1, *gamma2, *beta2;     /* f32 */
+    const void *wqkv_t, *wo_t, *w1_t, *w2_t;   /* backward: bf16 transposed copies (D, 3D), (D, D), (D, F), (F, D) */
+    const void* x;                     /* (R, D) bf16 layer input */
+    void* y;                           /* (R, D) bf16 layer output (forward) */
+    void* saved;                       /* saved_bytes: activations kept for the backward */
+    void* scratch;
+    const void* dy;                    /* (R, D) bf16 gradient of y (backward) */
+    void* dx;                          /* (R, D) bf16 gradient of x (backward) */
+    float* grads;                      /* grad_floats f32 (backward) */
+} cwlt_encoder_layer;
+typedef struct cwlt_encoder_layer_plan_t {
+    int64_t saved_bytes, fwd_scratch_bytes, bwd_scratch_bytes, grad_floats;
+    int64_t grad_off[CWLT_LAYER_NGRADS];
+    int64_t saved_off[CWLT_LAYER_NSAVED];  /* byte offsets inside `saved` (tests): qkv, attention out, zinv, final state,
+                                            * s1, x1, mean1, rstd1, gd, g, s2, mean2, rstd2 */
+} cwlt_encoder_layer_plan_t;
+int cwlt_encoder_layer_plan(int64_t n_seq, int64_t len, int d_model, int d_ff, int n_heads, float p_drop,
+                            int want_backward, cwlt_encoder_layer_plan_t* plan);
+int cwlt_encoder_layer_fwd(const cwlt_encoder_layer* layer, void* stream);
+int cwlt_encoder_layer_bwd(const cwlt_encoder_layer* layer, void* stream);
+/* The whole stack -- fast_transformers' TransformerEncoder.forward loop over its layers (dqn_policy/model.py:232) -- in one
+ * host call: `layers` is a HOST array of n structs wired by the caller (layer i's y is layer i + 1's x; in the backward
+ * layer i's dx is layer i - 1's dy); forward runs them in order, backward in reverse. */
+int cwlt_encoder_fwd(const cwlt_encoder_layer* layers, int n, void* stream);
+int cwlt_encoder_bwd(const cwlt_encoder_layer* layers, int n, void* stream);
+
 /* ---- hipGraph hygiene (no counterpart in the reference, which has no graphs; used by the drop-in RL loops' replayed
  * steps) -------------------------------------------------------------------------------------------
  * Replace every MEMSET node of a captured, not yet instantiated hipGraph_t by a kernel node writing the same bytes (same

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 16
+ABI_VERSION = 17
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -36,6 +36,28 @@ class DecodeModel(ctypes.Structure):
                  ("nrows", ctypes.POINTER(ctypes.c_int)), ("w_in", ctypes.c_void_p), ("b_in", ctypes.c_void_p),
                  ("pe0", ctypes.c_void_p), ("layers", ctypes.POINTER(DecodeLayer)), ("lnf_w", ctypes.c_void_p),
                  ("lnf_b", ctypes.c_void_p), ("w_heads", ctypes.c_void_p), ("b_heads", ctypes.c_void_p)])
+
+
+LAYER_NGRADS = 12       # CWLT_LAYER_NGRADS
+LAYER_NSAVED = 13       # CWLT_LAYER_NSAVED
+
+
+class EncoderLayer(ctypes.Structure):
+    """cwlt_encoder_layer (include/cwlt.h)."""
+    _fields_ = ([("n_seq", ctypes.c_int64), ("len", ctypes.c_int64), ("d_model", ctypes.c_int32), ("d_ff", ctypes.c_int32),
+                 ("n_heads", ctypes.c_int32), ("want_backward", ctypes.c_int32), ("p_drop", ctypes.c_float),
+                 ("ln_eps", ctypes.c_float), ("attn_eps", ctypes.c_float), ("reserved", ctypes.c_int32),
+                 ("seed", ctypes.c_uint64 * 3), ("seed_base", ctypes.c_void_p)] +
+                [(n, ctypes.c_void_p) for n in ("wqkv", "wo", "w1", "w2", "bqkv", "bo", "b1", "b2", "gamma1", "beta1",
+                                                "gamma2", "beta2", "wqkv_t", "wo_t", "w1_t", "w2_t", "x", "y", "saved",
+                                                "scratch", "dy", "dx", "grads")])
+
+
+class EncoderLayerPlan(ctypes.Structure):
+    """cwlt_encoder_layer_plan_t (include/cwlt.h)."""
+    _fields_ = [("saved_bytes", ctypes.c_int64), ("fwd_scratch_bytes", ctypes.c_int64),
+                ("bwd_scratch_bytes", ctypes.c_int64), ("grad_floats", ctypes.c_int64),
+                ("grad_off", ctypes.c_int64 * LAYER_NGRADS), ("saved_off", ctypes.c_int64 * LAYER_NSAVED)]
 
 
 # name -> argtypes; restype is always int (status)
@@ -64,6 +86,13 @@ _SIGNATURES = {
                                                 _ptr, _ptr],
     "cwlt_gemm_bf16": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_gemm_bf16_tune": [_c_int, _ptr],
+    "cwlt_gemm_bf16_small": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_transpose_bf16_many": [_ptr, _ptr, _ptr, _c_int, _ptr],
+    "cwlt_encoder_layer_plan": [_c_i64, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_int, ctypes.POINTER(EncoderLayerPlan)],
+    "cwlt_encoder_layer_fwd": [ctypes.POINTER(EncoderLayer), _ptr],
+    "cwlt_encoder_layer_bwd": [ctypes.POINTER(EncoderLayer), _ptr],
+    "cwlt_encoder_fwd": [ctypes.POINTER(EncoderLayer), _c_int, _ptr],
+    "cwlt_encoder_bwd": [ctypes.POINTER(EncoderLayer), _c_int, _ptr],
     "cwlt_graph_replace_memset_nodes": [_ptr, _ptr],
     "cwlt_bias_gelu_dropout_bwd": [_ptr] * 6 + [_c_i64, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_posenc_dropout": [_ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_f32, _c_u64, _ptr, _c_int, _ptr],

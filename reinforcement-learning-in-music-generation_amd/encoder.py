@@ -20,7 +20,7 @@ import os
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 
 
 # CWLT_FUSED_FFN_BWD=0: keep the two-kernel FFN backward (hipBLASLt input-gradient GEMM + cwlt_bias_gelu_dropout_bwd)
@@ -69,10 +69,39 @@ class _EncoderLayerFn(torch.autograd.Function):
             bo_a, b2_a = bo.to(adt), b2.to(adt)
         g1f, be1f, g2f, be2f, b1f = (ops._f32(t) for t in (g1, be1, g2, be2, b1))
 
-        if ops.gemm_bf16_supported(x2, wqkv):
+        if shadow is not None and len(shadow) > 8:
+            # steps of a few thousand token rows: the whole layer is ONE host call (csrc/layer.hip) -- the same kernels,
+            # enqueued from C; what the backward needs stays in one `saved` buffer
+            cache, li = shadow[8], shadow[9]
+            F = w1_a.shape[0]
+            plan = ops.layer_plan(N, L, D, F, H, p, will_backward)
+            x2 = x2.contiguous()
+            saved = torch.empty(plan.saved_bytes, dtype=torch.uint8, device=x.device)
+            out = torch.empty((R, D), dtype=adt, device=x.device)
+            st = _lib.EncoderLayer(n_seq=N, len=L, d_model=D, d_ff=F, n_heads=H, want_backward=1 if will_backward else 0,
+                                   p_drop=p, ln_eps=ops.LN_EPS, attn_eps=ops.CLA_EPS)
+            st.seed[0], st.seed[1], st.seed[2] = seeds
+            sb = ops._seed_base()
+            st.seed_base = sb.value if sb is not None else None
+            st.wqkv, st.wo, st.w1, st.w2 = (t.data_ptr() for t in (wqkv, wo_a, w1_a, w2_a))
+            st.bqkv, st.bo, st.b1, st.b2 = (t.data_ptr() for t in (bqkv32, ops._f32(bo), b1f, ops._f32(b2)))
+            st.gamma1, st.beta1, st.gamma2, st.beta2 = (t.data_ptr() for t in (g1f, be1f, g2f, be2f))
+            st.x, st.y, st.saved = x2.data_ptr(), out.data_ptr(), saved.data_ptr()
+            st.scratch = cache.get_scratch(plan.fwd_scratch_bytes).data_ptr()
+            ops.encoder_layer_fwd(st)
+            if will_backward:
+                ctx.c = (plan, saved, st, cache, li, x2, F)
+                ctx.cfg = (N, L, D, H, p, seeds)
+                ctx.layer = layer
+            return out.view(N, L, D)
+        ctx.c = None
+
+        small = ops.gemm_small_per_op(x2)          # test switch: the per-op path on cwlt_gemm_bf16_small (what the
+                                                    # one-call layer uses), so that the two can be compared bit for bit
+        if small or ops.gemm_bf16_supported(x2, wqkv):
             if bqkv32 is None:
                 bqkv32 = torch.cat([ops._f32(bq), ops._f32(bk), ops._f32(bv)])
-            qkv = ops.gemm_bf16(x2, wqkv, bqkv32)                          # (R, 3D)  MFMA
+            qkv = (ops.gemm_bf16_small if small else ops.gemm_bf16)(x2, wqkv, bqkv32)      # (R, 3D)  MFMA
         else:
             qkv = torch.addmm(bqkv, x2, wqkv.t())
         qkv5 = qkv.view(N, L, 3, H, D // H)
@@ -86,7 +115,8 @@ class _EncoderLayerFn(torch.autograd.Function):
             # reaches HBM (ops.linear_ln; the bias enters in f32)
             s1, x1, mean1, rstd1 = ops.linear_ln(a2, wo_a, ops._f32(bo), x2, g1f, be1f, ops.LN_EPS, p, seeds[0])
         else:
-            o = (ops.gemm_bf16(a2, wo_a, ops._f32(bo)) if ops.gemm_bf16_supported(a2, wo_a)
+            o = (ops.gemm_bf16_small(a2, wo_a, ops._f32(bo)) if small
+                 else ops.gemm_bf16(a2, wo_a, ops._f32(bo)) if ops.gemm_bf16_supported(a2, wo_a)
                  else torch.addmm(bo_a, a2, wo_a.t()))                     # MFMA
             s1, x1, mean1, rstd1 = ops.ln_fwd(x2, o, g1f, be1f, ops.LN_EPS, p, seeds[0])
             del o
@@ -99,14 +129,16 @@ class _EncoderLayerFn(torch.autograd.Function):
         if fused_ffn and FUSED_FFN_FWD and ops.ffn1_fused_supported(x1, w1_a, b1f):
             g, h = ops.ffn1_gelu_dropout(x1, w1_a, b1f, p, seeds[1])      # h holds gd
         else:
-            h = (ops.gemm_bf16(x1, w1_a) if ops.gemm_bf16_supported(x1, w1_a)
+            h = (ops.gemm_bf16_small(x1, w1_a) if small
+                 else ops.gemm_bf16(x1, w1_a) if ops.gemm_bf16_supported(x1, w1_a)
                  else torch.mm(x1, w1_a.t()))                              # (R, F)  MFMA, bias in next kernel
             fused_ffn = fused_ffn and h.is_contiguous()
             g = ops.gelu_fwd(h, b1f, p, seeds[1], gd_inplace=fused_ffn)
         if ops.linear_ln_supported(g, w2_a, x1):
             s2, out, mean2, rstd2 = ops.linear_ln(g, w2_a, ops._f32(b2), x1, g2f, be2f, ops.LN_EPS, p, seeds[2])
         else:
-            y = (ops.gemm_bf16(g, w2_a, ops._f32(b2)) if ops.gemm_bf16_supported(g, w2_a)
+            y = (ops.gemm_bf16_small(g, w2_a, ops._f32(b2)) if small
+                 else ops.gemm_bf16(g, w2_a, ops._f32(b2)) if ops.gemm_bf16_supported(g, w2_a)
                  else torch.addmm(b2_a, g, w2_a.t()))                      # MFMA
             s2, out, mean2, rstd2 = ops.ln_fwd(x1, y, g2f, be2f, ops.LN_EPS, p, seeds[2])
             del y
@@ -123,6 +155,29 @@ class _EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        if ctx.c is not None:
+            plan, saved, st, cache, li, x2, F = ctx.c
+            N, L, D, H, p, seeds = ctx.cfg
+            R = N * L
+            dout2 = dout.reshape(R, D).contiguous()
+            dx = torch.empty((R, D), dtype=dout2.dtype, device=dout2.device)
+            grads = torch.empty(plan.grad_floats, dtype=torch.float32, device=dout2.device)
+            st.wqkv_t, st.wo_t, st.w1_t, st.w2_t = (t.data_ptr() for t in cache.views[4 * li:4 * li + 4])
+            st.dy, st.dx, st.grads = dout2.data_ptr(), dx.data_ptr(), grads.data_ptr()
+            st.scratch = cache.get_scratch(plan.bwd_scratch_bytes).data_ptr()
+            ops.encoder_layer_bwd(st)
+            ctx.c = None
+            go = plan.grad_off
+
+            def gv(i, *shape):
+                n = 1
+                for d_ in shape:
+                    n *= d_
+                return grads[go[i]:go[i] + n].view(shape)
+
+            return _EncoderLayerFn._hand_over(ctx.layer, dx.view(N, L, D), D, gv(0, 3 * D, D), gv(1, 3 * D), gv(2, D, D),
+                                              gv(3, D), gv(4, F, D), gv(5, F), gv(6, D, F), gv(7, D), gv(8, D), gv(9, D),
+                                              gv(10, D), gv(11, D))
         x2, qkv, a, zinv, s1, mean1, rstd1, x1, h, g, s2, mean2, rstd2, g1f, g2f, b1f = ctx.saved_tensors
         wqkv, wo_a, w1_a, w2_a = ctx.weights
         N, L, D, H, p, seeds = ctx.cfg
@@ -143,7 +198,11 @@ class _EncoderLayerFn(torch.autograd.Function):
 
         # bf16 at training sizes: cwlt_gemm_bf16 on the transposed weight (both operands K-contiguous; a 0.5-2 MB copy),
         # `out` = the residual gradient the product is added onto
+        small = ops.gemm_small_per_op(dout2)
+
         def dgrad(g_, w_, out=None):
+            if small:
+                return ops.gemm_bf16_small(g_, w_.t().contiguous(), out=out, accumulate=out is not None)
             if ops.gemm_bf16_supported(g_, w_.t(), out, transposed_w=True):
                 return ops.gemm_bf16(g_, w_.t().contiguous(), out=out, accumulate=out is not None)
             if out is not None:
@@ -177,14 +236,20 @@ class _EncoderLayerFn(torch.autograd.Function):
                                   want_colsum=True, final_state=ctx.fin)
         ctx.fin = None
         dqkv2 = dqkv.view(R, 3 * D)
-        if ops.gemm_bf16_supported(dqkv2, wqkv.t(), ds1, transposed_w=True):
+        if small:
+            dx = ops.gemm_bf16_small(dqkv2, wqkv.t().contiguous(), out=ds1, accumulate=True)
+        elif ops.gemm_bf16_supported(dqkv2, wqkv.t(), ds1, transposed_w=True):
             dx = ops.gemm_bf16(dqkv2, wqkv.t().contiguous(), out=ds1, accumulate=True)
         else:
             dx = ds1.addmm_(dqkv2, wqkv)                                   # residual + projection gradient, in place
                                                                            # (NN is hipBLASLt's faster form for this shape)
                                                                            # (out-of-place addmm first copies ds1: 268 MB)
         dwqkv = wgrad(dqkv2, x2)                                           # (3D, D)
-        layer = ctx.layer
+        return _EncoderLayerFn._hand_over(ctx.layer, dx.view(N, L, D), D, dwqkv, dbqkv, dwo, dbo, dw1, db1, dw2, db2, dg1,
+                                          dbe1, dg2, dbe2)
+
+    @staticmethod
+    def _hand_over(layer, dx, D, dwqkv, dbqkv, dwo, dbo, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2):
         if layer is not None and ops.direct_grads(layer.linear1.weight):
             # write the 16 parameter gradients straight into .grad (flat f32 buckets) with one multi-tensor
             # convert+store, instead of .float() + autograd's accumulate; under data parallelism the buckets
@@ -198,12 +263,101 @@ class _EncoderLayerFn(torch.autograd.Function):
                                (layer.linear2.weight, dw2), (layer.linear2.bias, db2),
                                (layer.norm1.weight, dg1), (layer.norm1.bias, dbe1),
                                (layer.norm2.weight, dg2), (layer.norm2.bias, dbe2)))
-            return (dx.view(N, L, D),) + (None,) * 22
+            return (dx,) + (None,) * 22
         dwqkv = dwqkv.float()
-        return (dx.view(N, L, D),
+        return (dx,
                 dwqkv[:D], dbqkv[:D], dwqkv[D:2 * D], dbqkv[D:2 * D], dwqkv[2 * D:], dbqkv[2 * D:],
                 dwo.float(), dbo, dw1.float(), db1, dw2.float(), db2, dg1, dbe1, dg2, dbe2,
                 None, None, None, None, None, None)
+
+
+def _layer_params(layer):
+    """The 16 parameters of one layer in the order _EncoderLayerFn takes them."""
+    at = layer.attention
+    return (at.query_projection.weight, at.query_projection.bias, at.key_projection.weight, at.key_projection.bias,
+            at.value_projection.weight, at.value_projection.bias, at.out_projection.weight, at.out_projection.bias,
+            layer.linear1.weight, layer.linear1.bias, layer.linear2.weight, layer.linear2.bias,
+            layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias)
+
+
+class _EncoderStackFn(torch.autograd.Function):
+    """All layers of a TransformerEncoder as ONE autograd node and one host call each way (csrc/layer.hip:
+    cwlt_encoder_fwd / _bwd): the same kernels as _EncoderLayerFn's one-call branch, without a Python-level node,
+    allocations and seed draws per layer.  Used for steps of a few thousand token rows (TransformerEncoder._layer_c_ok).
+    What does not change between calls (weight / transposed-weight / stacked-bias pointers, layer dims, the flat
+    parameter list, the gradient views) lives in the encoder's ops.LayerCache."""
+
+    @staticmethod
+    def forward(ctx, x, enc, cache, grad_mode, *params):
+        will_backward = bool(grad_mode) and any(ctx.needs_input_grad)
+        arr = cache.arr
+        n = len(arr)
+        N, L, D = x.shape
+        R = N * L
+        _, F, H = cache.dims
+        p = enc.layers[0].dropout.p if enc.training else 0.0
+        plan = ops.layer_plan(N, L, D, F, H, p, will_backward)
+        dev = x.device
+        x2 = x.reshape(R, D).contiguous()
+        acts = torch.empty((n, R, D), dtype=x.dtype, device=dev)
+        saved = torch.empty((n, plan.saved_bytes), dtype=torch.uint8, device=dev)
+        seeds = ops.next_seeds(3 * n) if p > 0 else [0] * (3 * n)
+        sb = ops._seed_base()
+        sb = sb.value if sb is not None else None
+        scratch = cache.get_scratch(plan.fwd_scratch_bytes).data_ptr()
+        xp, ap, sp, sstride, astride = x2.data_ptr(), acts.data_ptr(), saved.data_ptr(), plan.saved_bytes, R * D * 2
+        wb = 1 if will_backward else 0
+        vec = [t.data_ptr() for t in params]                      # f32 master parameters: bias / gamma / beta pointers
+        for i in range(n):
+            st = arr[i]
+            o = 16 * i
+            st.n_seq, st.len, st.want_backward, st.p_drop, st.seed_base = N, L, wb, p, sb
+            st.seed[0], st.seed[1], st.seed[2] = seeds[3 * i:3 * i + 3]
+            st.bo, st.b1, st.b2 = vec[o + 7], vec[o + 9], vec[o + 11]
+            st.gamma1, st.beta1, st.gamma2, st.beta2 = vec[o + 12:o + 16]
+            st.x = xp if i == 0 else ap + (i - 1) * astride
+            st.y = ap + i * astride
+            st.saved = sp + i * sstride
+            st.scratch = scratch
+        ops.encoder_fwd(arr, n)
+        if will_backward:
+            ctx.c = (plan, saved, acts, x2, cache, seeds, sb, (N, L, D, p), vec)
+        return acts[n - 1].view(N, L, D)
+
+    @staticmethod
+    def backward(ctx, dout):
+        plan, saved, acts, x2, cache, seeds, sb, (N, L, D, p), vec = ctx.c
+        ctx.c = None
+        arr = cache.arr
+        n = len(arr)
+        R = N * L
+        dout2 = dout.reshape(R, D).contiguous()
+        dxs = torch.empty((n, R, D), dtype=dout2.dtype, device=dout2.device)
+        grads, views = cache.grad_buffer(plan)
+        gf = plan.grad_floats
+        scratch = cache.get_scratch(plan.bwd_scratch_bytes).data_ptr()
+        xp, ap, sp, sstride, astride = x2.data_ptr(), acts.data_ptr(), saved.data_ptr(), plan.saved_bytes, R * D * 2
+        dp, gp, dyp = dxs.data_ptr(), grads.data_ptr(), dout2.data_ptr()
+        for i in range(n):
+            # every per-call field again: another forward of this encoder may have run since (PPO: two actor passes before
+            # one backward)
+            st = arr[i]
+            o = 16 * i
+            st.n_seq, st.len, st.want_backward, st.p_drop, st.seed_base = N, L, 1, p, sb
+            st.seed[0], st.seed[1], st.seed[2] = seeds[3 * i:3 * i + 3]
+            st.gamma1, st.gamma2 = vec[o + 12], vec[o + 14]
+            st.x = xp if i == 0 else ap + (i - 1) * astride
+            st.saved = sp + i * sstride
+            st.dy = dyp if i == n - 1 else dp + (i + 1) * astride
+            st.dx = dp + i * astride
+            st.grads = gp + i * gf * 4
+            st.scratch = scratch
+        ops.encoder_bwd(arr, n)
+        dx = dxs[0].view(N, L, D)
+        if ops.direct_grads(cache.params[8]):
+            ops.deliver_grads_flat(cache.params, views, cache.all_need_grad)
+            return (dx, None, None, None) + (None,) * (16 * n)
+        return (dx, None, None, None) + tuple(v.clone() for v in views)
 
 
 class AttentionLayer(nn.Module):
@@ -257,6 +411,24 @@ class TransformerEncoder(nn.Module):
         self.norm = norm_layer
         self._shadow = None                                  # ops.ShadowSet of the layers' compute-dtype weights
         self._shadow32 = None                                # ... and of the stacked Q/K/V biases in f32 (bf16 mode)
+        self._cache = None                                   # ops.LayerCache of the one-call layers (few token rows)
+
+    def _layer_c_ok(self, x):
+        """Whether this forward runs its layers as one host call each (csrc/layer.hip): bf16, at most
+        ops.LAYER_C_MAX_ROWS token rows, the repo's layer shape, f32 master parameters."""
+        if not (ops.LAYER_C and x.dtype == torch.bfloat16 and 0 < x.shape[0] * x.shape[1] <= ops.LAYER_C_MAX_ROWS
+                and x.shape[2] == 512 and len(self.layers) > 0):
+            return False
+        ok = getattr(self, "_layer_c_params", None)
+        if ok is None:
+            l0 = self.layers[0]
+            ok = all(layer.attention.n_heads == 8 and layer.linear1.weight.shape[0] % 256 == 0
+                     and layer.linear1.weight.shape == l0.linear1.weight.shape and layer.dropout.p == l0.dropout.p
+                     and layer.linear1.weight.shape[1] == 512
+                     and all(q.dtype == torch.float32 and q.is_contiguous() for q in layer.parameters())
+                     for layer in self.layers)
+            self._layer_c_params = ok
+        return ok
 
     def forward(self, x, attn_mask=None, length_mask=None):
         if length_mask is not None:
@@ -269,14 +441,38 @@ class TransformerEncoder(nn.Module):
             sh = self._shadow = ops.ShadowSet([g for layer in self.layers for g in layer.shadow_groups()], x.dtype)
         bufs = sh.refresh()
         bufs32 = None
-        if x.dtype == torch.bfloat16 and x.shape[0] * x.shape[1] >= ops.GEMM_BF16_MIN_ROWS and ops.GEMM_BF16:
+        cache = None
+        if self._layer_c_ok(x):
+            # few token rows: one host call per layer (csrc/layer.hip); with a backward to come, the transposed weight
+            # copies of all layers are refreshed by one launch
+            cache = self._cache
+            if cache is None or cache.owner is not sh:
+                cache = self._cache = ops.LayerCache([bufs[per * i + j] for i in range(len(self.layers))
+                                                      for j in (0, 2, 4, 5)], sh)
+            if torch.is_grad_enabled():
+                cache.refresh_transposed()
+        if x.dtype == torch.bfloat16 and (cache is not None or (x.shape[0] * x.shape[1] >= ops.GEMM_BF16_MIN_ROWS
+                                                                and ops.GEMM_BF16)):
             s32 = self._shadow32
             if s32 is None or not s32.matches(torch.float32, x.device):
                 s32 = self._shadow32 = ops.ShadowSet([layer.shadow_groups()[1] for layer in self.layers], torch.float32)
             bufs32 = s32.refresh()
-        for i, layer in enumerate(self.layers):
-            sh_i = tuple(bufs[per * i:per * (i + 1)])
-            x = layer(x, attn_mask, sh_i + (bufs32[i],) if bufs32 is not None else sh_i)
+        if cache is not None and ops.LAYER_C_STACK:
+            if attn_mask is not None and not getattr(attn_mask, "lower_triangular", False):
+                raise RuntimeError("CausalLinearAttention only supports full lower triangular masks")
+            if getattr(cache, "qkv_bias_owner", None) is not bufs32:
+                cache.setup_stack([q for layer in self.layers for q in _layer_params(layer)],
+                                  [bufs[per * i + j] for i in range(len(self.layers)) for j in (0, 2, 4, 5)], bufs32,
+                                  (x.shape[2], self.layers[0].linear1.weight.shape[0], self.layers[0].attention.n_heads))
+            x = _EncoderStackFn.apply(x, self, cache, torch.is_grad_enabled(), *cache.params)
+        else:
+            for i, layer in enumerate(self.layers):
+                sh_i = tuple(bufs[per * i:per * (i + 1)])
+                if cache is not None:
+                    sh_i = sh_i + (bufs32[i], cache, i)
+                elif bufs32 is not None:
+                    sh_i = sh_i + (bufs32[i],)
+                x = layer(x, attn_mask, sh_i)
         if self.norm is not None:
             x = ops.layer_norm(x, self.norm.weight, self.norm.bias, self.norm.eps)
         return x

@@ -148,6 +148,21 @@ def deliver_grads(pairs):
             ready(p)
 
 
+def deliver_grads_flat(params, grads, all_need_grad):
+    """deliver_grads for a cached flat parameter list and its gradient views (encoder._EncoderStackFn): no per-pair
+    Python work on the common path (every parameter trainable and already holding a .grad buffer)."""
+    dst = [q.grad for q in params]
+    if not all_need_grad or any(g is None for g in dst):
+        return deliver_grads(list(zip(params, grads)))
+    torch._foreach_add_(dst, grads)
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        for q in params:
+            ready = getattr(q, "_cwlt_ready", None)
+            if ready is not None:
+                ready(q)
+
+
 _seed_counter = [0]
 
 
@@ -155,6 +170,12 @@ def next_seed():
     """Fresh 62-bit dropout key from torch's CPU generator (reproducible under torch.manual_seed)."""
     _seed_counter[0] += 1
     return int(torch.empty((), dtype=torch.int64).random_().item()) & ((1 << 62) - 1)
+
+
+def next_seeds(k):
+    """k dropout keys in one draw: the same values as k calls of next_seed() (one generator call per element, in order)."""
+    _seed_counter[0] += k
+    return [v & ((1 << 62) - 1) for v in torch.empty(k, dtype=torch.int64).random_().tolist()]
 
 
 # A captured hipGraph bakes every kernel argument, dropout seeds included.  The dropout kernels therefore accept
@@ -680,6 +701,158 @@ def gemm_bf16(a, w, bias=None, out=None, accumulate=False):
     _call("cwlt_gemm_bf16", _lib.dev(a, "a"), _lib.dev(w, "w"), _lib.opt(bias), _lib.dev(out, "out"), M, N, K, a.stride(0),
           w.stride(0), out.stride(0), 1 if accumulate else 0, _lib.stream_ptr(), work=2.0 * M * N * K)
     return out
+
+
+# one encoder layer per host call (csrc/layer.hip, below): CWLT_LAYER_C=0 keeps the per-op path at every size
+LAYER_C = os.environ.get("CWLT_LAYER_C", "1") != "0"
+LAYER_C_MAX_ROWS = int(os.environ.get("CWLT_LAYER_C_MAX_ROWS", 8192))
+# ... and the whole stack of an encoder per host call (one autograd node); CWLT_LAYER_C_STACK=0: one call per layer
+LAYER_C_STACK = os.environ.get("CWLT_LAYER_C_STACK", "1") != "0"
+# CWLT_GEMM_SMALL_PER_OP=1 (tests): the per-op encoder layer takes its plain projections from cwlt_gemm_bf16_small instead
+# of hipBLASLt whenever its rows are few enough for the one-call layer -- then the two paths run the same kernels
+GEMM_SMALL_PER_OP = os.environ.get("CWLT_GEMM_SMALL_PER_OP", "0") == "1"
+
+
+def gemm_small_per_op(x):
+    return GEMM_SMALL_PER_OP and x.dtype == torch.bfloat16 and x.dim() == 2 and 0 < x.shape[0] <= LAYER_C_MAX_ROWS
+
+
+def gemm_bf16_small(a, w, bias=None, out=None, accumulate=False):
+    """`gemm_bf16` for few rows (csrc/gemm_small.hip: 64 x 64 output tiles, operands straight from L2): K % 32 == 0."""
+    _lib.load()
+    M, K = a.shape
+    N = w.shape[0]
+    if out is None:
+        if accumulate:
+            raise ValueError("gemm_bf16_small: accumulate needs the tensor to add onto")
+        out = torch.empty((M, N), dtype=a.dtype, device=a.device)
+    _call("cwlt_gemm_bf16_small", _lib.dev(a, "a"), _lib.dev(w, "w"), _lib.opt(bias), _lib.dev(out, "out"), M, N, K,
+          a.stride(0), w.stride(0), out.stride(0), 1 if accumulate else 0, _lib.stream_ptr(), work=2.0 * M * N * K)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------
+# one encoder layer per host call (csrc/layer.hip): steps of a few thousand token rows are bound by the HOST when every
+# kernel is its own Python-level call (the reference's RL updates: 30 windows x 50 tokens, ~970 launches)
+# --------------------------------------------------------------------------------------------------
+_LAYER_PLANS = {}
+
+
+def layer_plan(N, L, D, F, H, p, want_backward):
+    """cwlt_encoder_layer_plan, cached: buffer sizes and gradient offsets of one layer call."""
+    key = (N, L, D, F, H, p > 0, bool(want_backward))
+    plan = _LAYER_PLANS.get(key)
+    if plan is None:
+        plan = _lib.EncoderLayerPlan()
+        _lib.check(_lib.load().cwlt_encoder_layer_plan(N, L, D, F, H, float(p), 1 if want_backward else 0,
+                                                       ctypes.byref(plan)), "cwlt_encoder_layer_plan")
+        _LAYER_PLANS[key] = plan
+    return plan
+
+
+class LayerCache:
+    """What the one-call layers of ONE encoder share: the transposed bf16 weight copies the input-gradient products
+    read (all matrices refreshed by one launch, cwlt_transpose_bf16_many) and a scratch buffer (every layer call of
+    an encoder runs on the launch stream, one after the other).  `mats`: the bf16 weight buffers, four per layer."""
+
+    def __init__(self, mats, owner):
+        self.owner = owner                       # the ShadowSet the buffers belong to (identity = validity)
+        dev = mats[0].device
+        self.flat = torch.empty(sum(m.numel() for m in mats), dtype=torch.bfloat16, device=dev)
+        self.base = mats[0]
+        rows, self.views, o = [], [], 0
+        for m in mats:
+            if m.dtype != torch.bfloat16 or not m.is_contiguous() or m.dim() != 2:
+                raise ValueError("LayerCache: dense 2-d bf16 weight buffers expected")
+            rows.append(((m.data_ptr() - self.base.data_ptr()) // 2, o, m.shape[0], m.shape[1]))
+            self.views.append(self.flat[o:o + m.numel()].view(m.shape[1], m.shape[0]))
+            o += m.numel()
+        self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        self.n = len(mats)
+        self.scratch = None
+        self.fresh_in = -1
+
+    def __reduce__(self):
+        return (_no_shadow, ())                  # a cache, as ShadowSet: copies of a model rebuild it
+
+    def refresh_transposed(self):
+        scope = _FROZEN[0]
+        if scope and self.fresh_in == scope and not torch.cuda.is_current_stream_capturing():
+            return
+        _call("cwlt_transpose_bf16_many", _lib.dev(self.base), _lib.dev(self.flat), _lib.dev(self.table), self.n,
+              _lib.stream_ptr())
+        self.fresh_in = scope if scope else -1
+
+    def setup_stack(self, layer_params, weights, qkv_bias, dims):
+        """Whole-stack calls (encoder._EncoderStackFn): a persistent HOST array of cwlt_encoder_layer structs with
+        everything that does not change from call to call filled in once -- dims = (d_model, d_ff, n_heads), the bf16
+        weight buffers (four per layer, persistent ShadowSet storage), their transposed copies, the stacked f32 Q/K/V
+        biases -- and the flat list of the layers' parameters (16 per layer, encoder._layer_params order)."""
+        n = len(qkv_bias)
+        arr = (_lib.EncoderLayer * n)()
+        D, F, H = dims
+        for i in range(n):
+            st = arr[i]
+            st.d_model, st.d_ff, st.n_heads, st.ln_eps, st.attn_eps = D, F, H, LN_EPS, CLA_EPS
+            st.wqkv, st.wo, st.w1, st.w2 = (t.data_ptr() for t in weights[4 * i:4 * i + 4])
+            st.wqkv_t, st.wo_t, st.w1_t, st.w2_t = (t.data_ptr() for t in self.views[4 * i:4 * i + 4])
+            st.bqkv = qkv_bias[i].data_ptr()
+        self.arr = arr
+        self.params = list(layer_params)
+        self.all_need_grad = all(q.requires_grad for q in self.params)
+        self.dims = dims
+        self.qkv_bias_owner = qkv_bias
+        self._grads = None
+
+    def grad_buffer(self, plan):
+        """(grads, views): a persistent f32 buffer for the parameter gradients of one backward of the whole stack and the
+        view of each parameter's gradient in it, in the order of self.params."""
+        n = len(self.arr)
+        gf = plan.grad_floats
+        got = self._grads
+        if got is None or got[0].numel() != n * gf or torch.cuda.is_current_stream_capturing():
+            D, F, _ = self.dims
+            grads = torch.empty(n * gf, dtype=torch.float32, device=self.flat.device)
+            go = list(plan.grad_off)
+            views = []
+            for i in range(n):
+                def gv(j, *shape):
+                    m = 1
+                    for d_ in shape:
+                        m *= d_
+                    return grads[i * gf + go[j]:i * gf + go[j] + m].view(shape)
+                wqkv, bqkv = gv(0, 3 * D, D), gv(1, 3 * D)
+                # q / k / v weight (bias) gradients are the row blocks of the stacked ones
+                views += [wqkv[:D], bqkv[:D], wqkv[D:2 * D], bqkv[D:2 * D], wqkv[2 * D:], bqkv[2 * D:], gv(2, D, D), gv(3, D),
+                          gv(4, F, D), gv(5, F), gv(6, D, F), gv(7, D), gv(8, D), gv(9, D), gv(10, D), gv(11, D)]
+            got = (grads, views)
+            if not torch.cuda.is_current_stream_capturing():
+                self._grads = got
+        return got
+
+    def get_scratch(self, nbytes):
+        dev = self.flat.device
+        if torch.cuda.is_current_stream_capturing():
+            return torch.empty(max(1, nbytes), dtype=torch.uint8, device=dev)     # lives in the graph's pool
+        if self.scratch is None or self.scratch.numel() < nbytes:
+            self.scratch = torch.empty(max(1, nbytes), dtype=torch.uint8, device=dev)
+        return self.scratch
+
+
+def encoder_fwd(arr, n):
+    _call("cwlt_encoder_fwd", arr, n, _lib.stream_ptr())
+
+
+def encoder_bwd(arr, n):
+    _call("cwlt_encoder_bwd", arr, n, _lib.stream_ptr())
+
+
+def encoder_layer_fwd(st):
+    _call("cwlt_encoder_layer_fwd", ctypes.byref(st), _lib.stream_ptr())
+
+
+def encoder_layer_bwd(st):
+    _call("cwlt_encoder_layer_bwd", ctypes.byref(st), _lib.stream_ptr())
 
 
 def gemm_nt_mul_supported(a, w, g):
