@@ -205,6 +205,100 @@ __global__ __launch_bounds__(256) void gemm_small_splitk_kernel(const bf16_t* __
     store4(cp, make_float4(v[0], v[1], v[2], v[3]));
 }
 
+// The same with a 64 x 64 output tile per workgroup (a wave: 4 x 4 MFMA tiles, 8 fragment loads per 16 MFMAs), for launches
+// with a few hundred rows or more: nothing is shared through LDS, so the bytes pulled from L2 are (rows + columns) x K x 2
+// per WAVE -- 144-192 MB per product at 1 500 rows with 32 x 32 tiles, which is what bounded them (13-25 us at ~8 TB/s);
+// the larger tile halves that.  Wave w finishes row block w (rows 16 w + l15): per 32-column half, 8 consecutive columns.
+template <bool BIAS, bool ACCUM, int PD>
+__global__ __launch_bounds__(256) void gemm_small_splitk64_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                                  const float* __restrict__ bias, bf16_t* C, long M, int N,
+                                                                  int K, long lda, long ldw, long ldc) {
+    __shared__ float red[4][64][64];
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int l15 = lane & 15, kg = lane >> 4;
+    const long m0 = (long)blockIdx.y * 64;
+    const int n0 = blockIdx.x * 64;
+    const long mr = min(64l, M - m0);
+    const int nr = min(64, N - n0);
+    const __amdgpu_buffer_rsrc_t ars = make_rsrc(A + m0 * lda, (uint32_t)(((mr - 1) * lda + K) * 2));
+    const __amdgpu_buffer_rsrc_t wrs = make_rsrc(W + (long)n0 * ldw, (uint32_t)(((long)(nr - 1) * ldw + K) * 2));
+    uint32_t a_off[4], w_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        a_off[i] = (uint32_t)(((16 * i + l15) * lda + 8 * kg) * 2);
+        w_off[i] = (uint32_t)(((32 * (i >> 1) + 8 * (l15 >> 2) + 4 * (i & 1) + (l15 & 3)) * ldw + 8 * kg) * 2);
+    }
+    bf16x8 fa[PD][4], fw[PD][4];
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nkw = K >> 7;
+    const int k0 = w * nkw;
+#define GS_LOAD(slot, ks)                                                                                       \
+    {                                                                                                           \
+        const int so_ = (k0 + (ks)) * 64;                                                                       \
+        _Pragma("unroll") for (int i_ = 0; i_ < 4; ++i_) {                                                      \
+            fa[slot][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(ars, (int)a_off[i_], so_, 0)); \
+            fw[slot][i_] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(wrs, (int)w_off[i_], so_, 0)); \
+        }                                                                                                       \
+    }
+#define GS_MFMA(slot)                                                                                           \
+    _Pragma("unroll") for (int mb_ = 0; mb_ < 4; ++mb_)                                                         \
+        _Pragma("unroll") for (int nb_ = 0; nb_ < 4; ++nb_)                                                     \
+            acc[mb_][nb_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[slot][nb_], fa[slot][mb_], acc[mb_][nb_], 0, 0, 0);
+    const int ngrp = nkw / PD;
+#pragma unroll
+    for (int s = 0; s < PD; ++s) GS_LOAD(s, s)
+    for (int g = 1; g < ngrp; ++g) {
+#pragma unroll
+        for (int s = 0; s < PD; ++s) {
+            GS_MFMA(s)
+            GS_LOAD(s, g * PD + s)
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < PD; ++s) GS_MFMA(s)
+#undef GS_MFMA
+#undef GS_LOAD
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 4; ++nb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) red[w][16 * mb + 4 * nb + r][lane] = acc[mb][nb][r];
+    __syncthreads();
+    const int row = 16 * w + l15;
+    if (row >= mr) return;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {                        // 32-column half: tiles nb = 2 q, 2 q + 1
+        const int col = 32 * q + 8 * kg;
+        if (col >= nr) continue;                         // N % 8 == 0
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int c = 16 * w + 4 * (2 * q + (j >> 2)) + (j & 3);
+            v[j] = (red[0][c][lane] + red[1][c][lane]) + (red[2][c][lane] + red[3][c][lane]);
+        }
+        bf16_t* cp = C + (m0 + row) * ldc + n0 + col;
+        if (ACCUM) {
+            float o[8];
+            load8(cp, o);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += o[j];
+        }
+        if (BIAS) {
+            float b[8];
+            loadf<8>(bias + n0 + col, b);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += b[j];
+        }
+        store8(cp, v);
+    }
+}
+
 // dst_i (cols_i, rows_i) = src_i (rows_i, cols_i)^T for every matrix of a table: int64 quadruples (src element offset,
 // dst element offset, rows, cols) in device memory, offsets relative to `src` / `dst`.  64 x 64 tiles through LDS.
 __global__ __launch_bounds__(256) void transpose_many_kernel(const bf16_t* __restrict__ src, bf16_t* __restrict__ dst,
@@ -265,6 +359,24 @@ int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* 
              gs::gemm_small_splitk_kernel<true, false, 4>, gs::gemm_small_splitk_kernel<true, false, 8>},
             {gs::gemm_small_splitk_kernel<true, true, 1>, gs::gemm_small_splitk_kernel<true, true, 2>,
              gs::gemm_small_splitk_kernel<true, true, 4>, gs::gemm_small_splitk_kernel<true, true, 8>}};
+        // from a few hundred rows on: 64 x 64 tiles (half the L2 traffic); PD <= 4 there (8 fragments per k-step)
+        static const int big_rows = [] { const char* e = getenv("CWLT_GEMM_SMALL_TILE64_ROWS"); return e ? atoi(e) : 256; }();
+        if (M >= big_rows) {
+            static const kfn_t tab64[4][3] = {
+                {gs::gemm_small_splitk64_kernel<false, false, 1>, gs::gemm_small_splitk64_kernel<false, false, 2>,
+                 gs::gemm_small_splitk64_kernel<false, false, 4>},
+                {gs::gemm_small_splitk64_kernel<false, true, 1>, gs::gemm_small_splitk64_kernel<false, true, 2>,
+                 gs::gemm_small_splitk64_kernel<false, true, 4>},
+                {gs::gemm_small_splitk64_kernel<true, false, 1>, gs::gemm_small_splitk64_kernel<true, false, 2>,
+                 gs::gemm_small_splitk64_kernel<true, false, 4>},
+                {gs::gemm_small_splitk64_kernel<true, true, 1>, gs::gemm_small_splitk64_kernel<true, true, 2>,
+                 gs::gemm_small_splitk64_kernel<true, true, 4>}};
+            const kfn_t kf64 = tab64[sel][pd >= 4 ? 2 : pd == 2 ? 1 : 0];
+            hipLaunchKernelGGL(kf64, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64)), dim3(256), 0,
+                               (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w, bias, (bf16_t*)c, (long)M, N, K,
+                               (long)lda, (long)ldw, (long)ldc);
+            return (int)hipGetLastError();
+        }
         const kfn_t kf = tab[sel][pd == 8 ? 3 : pd == 4 ? 2 : pd == 2 ? 1 : 0];
         hipLaunchKernelGGL(kf, dim3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)a, (const bf16_t*)w, bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw,

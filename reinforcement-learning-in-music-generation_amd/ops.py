@@ -227,6 +227,9 @@ def train_graphs_enabled():
     return GRAPHS_ENABLED and TRAIN_GRAPHS and single
 
 
+FUSED_ADAM = os.environ.get("CWLT_FUSED_ADAM", "1") != "0"
+
+
 def graph_adam(params, lr, **kw):
     """torch.optim.Adam as the reference constructs it; when training steps may be captured, `capturable=True`
     with the learning rate held in a device tensor, so an LR scheduler's updates reach the captured step.
@@ -237,6 +240,11 @@ def graph_adam(params, lr, **kw):
     if train_graphs_enabled() and params and params[0].is_cuda:
         return torch.optim.Adam(params, lr=torch.tensor(float(lr), device=params[0].device), capturable=True,
                                 fused=True, **kw)
+    # eager steps: the single-kernel ("fused") implementation of the same update -- the default multi-tensor one is
+    # eight passes over every parameter and state tensor per step (9 % of the GPU time of a window-50 PPO iteration,
+    # profiles/r04_ppo_w50_kernels.txt).  CWLT_FUSED_ADAM=0: torch's default implementation.
+    if FUSED_ADAM and params and all(q.is_cuda and q.dtype == torch.float32 for q in params):
+        return torch.optim.Adam(params, lr=lr, fused=True, **kw)
     return torch.optim.Adam(params, lr=lr, **kw)
 
 
