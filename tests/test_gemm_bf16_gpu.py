@@ -162,6 +162,7 @@ def test_encoder_on_the_hand_written_projections_equals_the_library_path(cuda, m
     x = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1).to(cuda)
     y = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1).to(cuda)
     mask = torch.ones(B, T, device=cuda)
+    monkeypatch.setattr(ops, "LAYER_C", False)                  # the per-op layer (512 rows would take the one-call path)
     monkeypatch.setattr(ops, "LINEAR_LN_MIN_ROWS", 1 << 40)    # the residual blocks as GEMM + LayerNorm kernel: their GEMMs
     runs = {}                                                   # (out-projection, linear2) then go through this switch too
     old = dict(config.AgentConfig)

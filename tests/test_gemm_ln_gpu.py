@@ -89,6 +89,7 @@ def test_encoder_with_the_one_kernel_residual_blocks_equals_the_two_kernel_path(
     x = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1).to(cuda)
     y = torch.stack([torch.randint(0, n, (B, T), generator=g) for n in n_class], -1).to(cuda)
     mask = torch.ones(B, T, device=cuda)
+    monkeypatch.setattr(ops, "LAYER_C", False)                  # the per-op layer (512 rows would take the one-call path)
     monkeypatch.setattr(ops, "LINEAR_LN_MIN_ROWS", 0)
     monkeypatch.setattr(ops, "LINEAR_LN_MAX_K", 4096)          # both residual blocks of a layer, K = 512 and K = 2048
     runs = {}
