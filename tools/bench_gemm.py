@@ -195,9 +195,9 @@ def main():
             t = sorted(t)
             med, mn = t[len(t) // 2], t[0]
             return "%7.1f us med %7.1f min (%4.0f TF)" % (med * 1e3, mn * 1e3, fl / med / 1e9)
-        lib = min(ts[:nlib], key=lambda t: sorted(t)[len(t) // 2])
-        line = "%-38s err %.1e | hipBLASLt%s %s" % (name, err, " (NT on a transposed copy)" if nlib == 2 and lib is ts[1]
-                                                    else " (NN)" if nlib == 2 else "", fmt(lib))
+        best = min(ts[:nlib], key=lambda t: sorted(t)[len(t) // 2])
+        line = "%-38s err %.1e | hipBLASLt%s %s" % (name, err, " (NT on a transposed copy)" if nlib == 2 and best is ts[1]
+                                                    else " (NN)" if nlib == 2 else "", fmt(best))
         for i, v in enumerate(variants):
             line += " | v%d %s" % (v, fmt(ts[nlib + i]))
         print(line, flush=True)
