@@ -54,7 +54,7 @@ SCAN_BWD_PARTS = ("cwlt_causal_linear_bwd", "cwlt_causal_linear_bwd_sweep", "cwl
 
 
 def algorithmic_bytes(entry, B, T, D=512, F=2048, H=8, s=2, ncat=1216, W=384):
-    """Algorithmic HBM bytes of ONE launch of a libcwlt entry point at this workload (DESIGN.md §Kernels; SURVEY §8d).
+    """Algorithmic HBM bytes of ONE launch of a libcwlt entry point at this workload (DESIGN.md §4; SURVEY §8d).
     s = bytes per activation element.  The attention backward is priced as ONE unit whatever its launch count:
     7 * D * s per token (Q, K, V, dOut read; dQ, dK, dV written) -- re-reads by a second kernel, and the one-sweep
     kernel's read of `out` (needed only for dden), are waste, not work.  Likewise the forward activation is priced at
