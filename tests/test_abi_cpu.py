@@ -147,3 +147,35 @@ def test_public_header_is_plain_c(tmp_path):
                 ["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", inc, "-x", "c++", str(src)]):
         r = subprocess.run(cmd, capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_encoder_layer_plan_and_refusals_without_gpu(built):
+    """cwlt_encoder_layer_plan is host arithmetic; the layer / stack calls refuse null pointers and shapes they do not
+    run before touching the device (include/cwlt.h, "a whole encoder layer per host call")."""
+    lib = built.load()
+    plan = built.EncoderLayerPlan()
+    assert lib.cwlt_encoder_layer_plan(30, 50, 512, 2048, 8, 0.1, 1, ctypes.byref(plan)) == 0
+    R = 1500
+    # saved: qkv (3D) + attention out, s1, x1, s2 (4D) + g, gd (2F) bf16 per row at least
+    assert plan.saved_bytes >= R * (3 * 512 + 4 * 512 + 2 * 2048) * 2
+    assert plan.saved_bytes % 256 == 0 and plan.fwd_scratch_bytes >= R * 512 * 2
+    assert plan.bwd_scratch_bytes >= R * (2048 + 3 * 512 + 2 * 512) * 2
+    offs, sizes = list(plan.grad_off), [3 * 512 * 512, 3 * 512, 512 * 512, 512, 2048 * 512, 2048, 512 * 2048, 512, 512, 512,
+                                        512, 512]
+    spans = sorted(zip(offs, sizes))
+    assert all(a + n <= b for (a, n), (b, _) in zip(spans, spans[1:]))          # the 12 gradients do not overlap
+    assert spans[-1][0] + spans[-1][1] <= plan.grad_floats
+    assert lib.cwlt_encoder_layer_plan(30, 50, 256, 2048, 8, 0.1, 1, ctypes.byref(plan)) == 1001       # d_model
+    assert lib.cwlt_encoder_layer_plan(30, 50, 512, 2000, 8, 0.1, 1, ctypes.byref(plan)) == 1001       # d_ff % 256
+    assert lib.cwlt_encoder_layer_plan(0, 50, 512, 2048, 8, 0.1, 1, ctypes.byref(plan)) == 1001        # no rows
+    st = built.EncoderLayer(n_seq=30, len=50, d_model=512, d_ff=2048, n_heads=8, want_backward=1, p_drop=0.1)
+    assert lib.cwlt_encoder_layer_fwd(ctypes.byref(st), None) == 1001
+    assert lib.cwlt_encoder_layer_bwd(ctypes.byref(st), None) == 1001
+    arr = (built.EncoderLayer * 2)()
+    assert lib.cwlt_encoder_fwd(arr, 2, None) == 1001 and lib.cwlt_encoder_bwd(arr, 2, None) == 1001
+    assert lib.cwlt_encoder_fwd(arr, 0, None) == 0                                # nothing to do
+    null = ctypes.c_void_p(0)
+    assert lib.cwlt_gemm_bf16_small(null, null, null, null, 8, 512, 512, 512, 512, 512, 0, null) == 1001
+    assert lib.cwlt_gemm_bf16_small(null, null, null, null, 0, 512, 512, 512, 512, 512, 0, null) == 0  # no rows
+    assert lib.cwlt_transpose_bf16_many(null, null, null, 3, null) == 1001
+
