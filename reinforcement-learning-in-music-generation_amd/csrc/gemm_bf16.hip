@@ -454,8 +454,11 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_kernel(const bf16_t* __restr
                         r[c] = f32x2_to_bf16x2(y[0], y[1]) & hw;
                         dq[c] = f32x2_to_bf16x2(dy[0], dy[1]) & hw;
                     }
-                    // g is the next GEMM's operand: default policy; gd waits for the backward: streamed past the caches
-                    __builtin_amdgcn_raw_buffer_store_b128(r, crs, (int)(c_voff[q] + mb * c_step), 0, 0);
+                    // both outputs are streamed past the caches: at the sizes this kernel runs at (>= 32 768 rows: 128 MiB
+                    // per output) neither survives in L2 / MALL until its reader, and with the default policy the 128 KiB of
+                    // g per tile pushed the A strips and W slices out of L2 between their uses (counter traffic of the
+                    // kernel 6.71 GB per launch against 4.83 algorithmic; variant bit 17 = default policy, for the A/B)
+                    __builtin_amdgcn_raw_buffer_store_b128(r, crs, (int)(c_voff[q] + mb * c_step), 0, (ABL & 16) ? 0 : 2);
                     __builtin_amdgcn_raw_buffer_store_b128(dq, grs, (int)(c_voff[q] + mb * c_step), 0, 2);
                 }
         } else {
@@ -610,7 +613,10 @@ static int launch_gemm_big(int epi, const void* a, const void* w, const float* b
         case 1: kfn = late ? gb::gemm_bf16_kernel<1, false, 0, false> : gb::gemm_bf16_kernel<1, false, 0, true>; break;
         case 2: kfn = late ? gb::gemm_bf16_kernel<2, false, 0, false> : gb::gemm_bf16_kernel<2, false, 0, true>; break;
         case 3: kfn = late ? gb::gemm_bf16_kernel<3, false, 0, false> : gb::gemm_bf16_kernel<3, false, 0, true>; break;
-        case gb::EPI_GELU: kfn = gb::gemm_bf16_kernel<gb::EPI_GELU, false, 0, true>; break;
+        case gb::EPI_GELU:
+            kfn = (var & (1 << 17)) ? gb::gemm_bf16_kernel<gb::EPI_GELU, false, 16, true>
+                                    : gb::gemm_bf16_kernel<gb::EPI_GELU, false, 0, true>;
+            break;
         case gb::EPI_MUL: kfn = gb::gemm_bf16_kernel<gb::EPI_MUL, false, 0, true>; break;
         default: return CWLT_ERR_ARG;
     }

@@ -103,6 +103,15 @@ def bench_ffn1():
     h = torch.mm(x, w1.t())
     t1 = timeit(lambda: ops.gelu_fwd(h, b, 0.1, 77, gd_inplace=True))
     t2 = timeit(lambda: ops.ffn1_gelu_dropout(x, w1, b, 0.1, 77))
+    var = os.environ.get("CWLT_GEMM_VARIANT")              # cwlt_gemm_bf16_tune bits (131072: g stored with the default policy)
+    if var:
+        from rlmg_amd import _lib
+        _lib.load().cwlt_gemm_bf16_tune(int(var), None)
+        t3 = [timeit(lambda: ops.ffn1_gelu_dropout(x, w1, b, 0.1, 77)) for _ in range(3)]
+        _lib.load().cwlt_gemm_bf16_tune(-1, None)
+        t4 = [timeit(lambda: ops.ffn1_gelu_dropout(x, w1, b, 0.1, 77)) for _ in range(3)]
+        print("       variant %s: %s us; default again: %s us" % (var, ["%.1f" % (t * 1e3) for t in t3],
+                                                                  ["%.1f" % (t * 1e3) for t in t4]))
     fl = 2.0 * M * 512 * 2048
     print("M=%d  unfused: mm %.1f us (%.0f TF) + activation with gd %.1f us = %.1f us" %
           (M, t0 * 1e3, fl / t0 / 1e9, t1 * 1e3, (t0 + t1) * 1e3))
