@@ -10,8 +10,11 @@
 // k-steps of 32, bias added in f32, one rounding to bf16.
 //
 // Long reductions (K = 1536, 2048) are a chain of 48-64 dependent k-steps for one wave; where K % 128 == 0 the four waves
-// of a workgroup instead split K four ways over ONE 32 x 32 output tile (752 workgroups at M = 1 500, N = 512) and add
-// their accumulators through LDS in a fixed order: a quarter of the chain, 21-27 -> ~8 us at those shapes.
+// of a workgroup instead split K four ways over ONE output tile and add their accumulators through LDS in a fixed order:
+// a quarter of the chain.  Below 256 rows the tile is 32 x 32 (a 50-row rollout step still gets 32 workgroups at
+// N = 512); from 256 rows it is 64 x 64, a wave holding 4 x 4 MFMA tiles: with nothing shared through LDS every wave pulls
+// (rows + columns) x K x 2 bytes from L2, 144-192 MB per product at 1 500 rows with the small tile -- that, not latency,
+// bounded it there (21-27 us whole-K, 20-25 us split-K on 32 x 32, 13-17 us on 64 x 64; profiles/r04_layer_call.txt).
 //
 // cwlt_transpose_bf16_many: the transposed weight copies the input-gradient products read (dX = dY . W is an NT
 // product on W^T), all matrices of an encoder in one launch.
