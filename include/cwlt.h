@@ -425,6 +425,12 @@ int cwlt_sample_categorical(const float* logits, const int* n_class, const float
 int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int64_t lda,
                          int64_t ldw, int64_t ldc, int accumulate, void* stream);
 int cwlt_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, void* stream);
+/* cwlt_gemm_nt_bias_gelu_dropout on the split-K small tiles, for passes of a few hundred rows at most (a 50-token rollout
+ * step): g = dropout_p(gelu(bf16(a . w^T) + bias)), and gd = mask / (1 - p) * gelu'(.) when gd != NULL -- what
+ * cwlt_gemm_bf16_small followed by cwlt_bias_gelu_dropout_fwd produce, bit for bit (same rounding of the product, same
+ * dropout stream keyed by (seed, row * N + column)).  g, gd dense (M, N); K % 128 == 0, N % 8 == 0. */
+int cwlt_gemm_bf16_small_gelu(const void* a, const void* w, const float* bias, void* g, void* gd, int64_t M, int N, int K,
+                              int64_t lda, int64_t ldw, float p, uint64_t seed, const uint64_t* seed_base, void* stream);
 
 /* One post-LN encoder layer -- fast_transformers' TransformerEncoderLayer(AttentionLayer(CausalLinearAttention)) as
  * built at dqn_policy/model.py:128-137 (ppo_policy/model.py:129-138) and called at :232:

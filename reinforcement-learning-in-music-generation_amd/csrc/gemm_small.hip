@@ -21,6 +21,7 @@
 #include <stdlib.h>
 
 #include "cwlt_common.h"
+#include "cwlt_gelu.h"
 
 namespace cwlt {
 namespace gs {
@@ -126,10 +127,20 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const bf16_t* __restric
 // Split-K form: workgroup = one 32 x 32 output tile, wave w = k-steps [w nks / 4, (w + 1) nks / 4), nks / 4 a multiple of
 // PD (all of a wave's groups are full).  Partial accumulators meet in LDS as [wave][component][lane] (lane-contiguous:
 // conflict-free); wave w then owns MFMA tile (mb, nb) = (w >> 1, w & 1): row 16 mb + l15, columns 8 kg + 4 nb .. + 3.
-template <bool BIAS, bool ACCUM, int PD>
+// GELU != 0 (FFN forward at few rows: x = bf16(a w^T) + bias; c = dropout(gelu(x)), gd = mask / (1 - p) * gelu'(x), the
+// arithmetic and dropout stream of cwlt_bias_gelu_dropout_fwd on the rounded product, element index row * N + column):
+// BIAS, no ACCUM, dense c / gd with row stride N.
+struct GeluArgs {
+    bf16_t* gd;                // NULL: not wanted (no backward will follow)
+    uint32_t thresh;
+    float keep_scale;
+    uint64_t seed;
+    const uint64_t* seed_base;
+};
+template <bool BIAS, bool ACCUM, int PD, bool GELU = false>
 __global__ __launch_bounds__(256) void gemm_small_splitk_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                                 const float* __restrict__ bias, bf16_t* C, long M, int N,
-                                                                int K, long lda, long ldw, long ldc) {
+                                                                int K, long lda, long ldw, long ldc, GeluArgs ga) {
     __shared__ float red[4][16][64];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -200,6 +211,29 @@ __global__ __launch_bounds__(256) void gemm_small_splitk_kernel(const bf16_t* __
     if (ACCUM) {
         const float4 o = load4(cp);
         v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+    }
+    if (GELU) {
+        const float4 b = load4(bias + n0 + col);
+        uint64_t seed = ga.seed;
+        if (ga.seed_base) seed += *ga.seed_base;
+        const GeluK gk = gelu_consts(ga.keep_scale);
+        const uint32_t thresh2 = ga.thresh | (ga.thresh << 16);
+        const uint64_t pair = ((uint64_t)(m0 + row) * (uint64_t)N + (uint64_t)(n0 + col)) >> 1;
+        const float bb[4] = {b.x, b.y, b.z, b.w};
+        uint32_t r[2], dq[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+            f32x2 x, y, dy;
+            x[0] = (float)(__bf16)v[2 * c] + bb[2 * c];
+            x[1] = (float)(__bf16)v[2 * c + 1] + bb[2 * c + 1];
+            gelu_scaled2(x, gk, y, dy);
+            const uint32_t hw = keep_lanes16(rng_pair(seed, pair + c), thresh2);
+            r[c] = f32x2_to_bf16x2(y[0], y[1]) & hw;
+            dq[c] = f32x2_to_bf16x2(dy[0], dy[1]) & hw;
+        }
+        *reinterpret_cast<uint2*>(cp) = make_uint2(r[0], r[1]);
+        if (ga.gd) *reinterpret_cast<uint2*>(ga.gd + (m0 + row) * ldc + n0 + col) = make_uint2(dq[0], dq[1]);
+        return;
     }
     if (BIAS) {
         const float4 b = load4(bias + n0 + col);
@@ -346,6 +380,8 @@ int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* 
     if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)c | (uintptr_t)bias) & 15) return CWLT_ERR_ARG;
     if (32 * lda * 2 >= (1ll << 31) || 32 * ldw * 2 >= (1ll << 31)) return CWLT_ERR_ARG;     // 32-bit offsets inside a wave tile
     typedef void (*kfn_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long);
+    typedef void (*kfng_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long,
+                           gs::GeluArgs);
     // split-K over the four waves where every wave gets whole groups of k-steps and the launch stays small (the form
     // re-reads each operand strip twice as often: meant for the few-thousand-row launches this file is for)
     static const int splitk = [] { const char* e = getenv("CWLT_GEMM_SMALL_SPLITK"); return e ? atoi(e) : 1; }();
@@ -353,7 +389,7 @@ int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* 
         const int nkw = K >> 7;
         const int pd = (nkw % 8) == 0 ? 8 : (nkw % 4) == 0 ? 4 : (nkw % 2) == 0 ? 2 : 1;
         const int sel = (bias ? 2 : 0) | (accumulate ? 1 : 0);
-        static const kfn_t tab[4][4] = {
+        static const kfng_t tab[4][4] = {
             {gs::gemm_small_splitk_kernel<false, false, 1>, gs::gemm_small_splitk_kernel<false, false, 2>,
              gs::gemm_small_splitk_kernel<false, false, 4>, gs::gemm_small_splitk_kernel<false, false, 8>},
             {gs::gemm_small_splitk_kernel<false, true, 1>, gs::gemm_small_splitk_kernel<false, true, 2>,
@@ -380,10 +416,10 @@ int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* 
                                (long)lda, (long)ldw, (long)ldc);
             return (int)hipGetLastError();
         }
-        const kfn_t kf = tab[sel][pd == 8 ? 3 : pd == 4 ? 2 : pd == 2 ? 1 : 0];
+        const kfng_t kf = tab[sel][pd == 8 ? 3 : pd == 4 ? 2 : pd == 2 ? 1 : 0];
         hipLaunchKernelGGL(kf, dim3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
                            (const bf16_t*)a, (const bf16_t*)w, bias, (bf16_t*)c, (long)M, N, K, (long)lda, (long)ldw,
-                           (long)ldc);
+                           (long)ldc, gs::GeluArgs{});
         return (int)hipGetLastError();
     }
     const long gy = (M + gs::TM - 1) / gs::TM;
@@ -393,6 +429,30 @@ int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* 
                            : (accumulate ? gs::gemm_small_kernel<false, true> : gs::gemm_small_kernel<false, false>);
     hipLaunchKernelGGL(kfn, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, (const bf16_t*)w, bias, (bf16_t*)c,
                        (long)M, N, K, (long)lda, (long)ldw, (long)ldc);
+    return (int)hipGetLastError();
+}
+
+/* FFN forward at few rows (see include/cwlt.h): g = dropout(gelu(bf16(a w^T) + bias)) and, when gd != NULL,
+ * gd = mask / (1 - p) * gelu'(.), dense (M, N).  K % 128 == 0, N % 8 == 0, M <= 65535 * 32. */
+int cwlt_gemm_bf16_small_gelu(const void* a, const void* w, const float* bias, void* g, void* gd, int64_t M, int N, int K,
+                              int64_t lda, int64_t ldw, float p, uint64_t seed, const uint64_t* seed_base, void* stream) {
+    using namespace cwlt;
+    if (M < 0 || N <= 0 || K < 128 || (N % 8) || (K % 128) || !(p >= 0.f && p < 1.f)) return CWLT_ERR_ARG;
+    if (M == 0) return CWLT_OK;
+    if (!a || !w || !bias || !g) return CWLT_ERR_ARG;
+    if (((lda | ldw) & 7) || lda < K || ldw < K) return CWLT_ERR_ARG;
+    if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)g | (uintptr_t)gd | (uintptr_t)bias) & 15) return CWLT_ERR_ARG;
+    if (32 * lda * 2 >= (1ll << 31) || 32 * ldw * 2 >= (1ll << 31) || (M + 31) / 32 > 65535) return CWLT_ERR_ARG;
+    typedef void (*kfng_t)(const bf16_t*, const bf16_t*, const float*, bf16_t*, long, int, int, long, long, long,
+                           gs::GeluArgs);
+    const int nkw = K >> 7;
+    const kfng_t kf = (nkw % 8) == 0   ? gs::gemm_small_splitk_kernel<true, false, 8, true>
+                      : (nkw % 4) == 0 ? gs::gemm_small_splitk_kernel<true, false, 4, true>
+                      : (nkw % 2) == 0 ? gs::gemm_small_splitk_kernel<true, false, 2, true>
+                                       : gs::gemm_small_splitk_kernel<true, false, 1, true>;
+    const gs::GeluArgs ga{(bf16_t*)gd, drop_thresh(p), drop_scale(p), seed, seed_base};
+    hipLaunchKernelGGL(kf, dim3((unsigned)((N + 31) / 32), (unsigned)((M + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)a, (const bf16_t*)w, bias, (bf16_t*)g, (long)M, N, K, (long)lda, (long)ldw, (long)N, ga);
     return (int)hipGetLastError();
 }
 

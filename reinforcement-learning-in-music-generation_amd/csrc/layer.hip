@@ -209,8 +209,15 @@ int cwlt_encoder_layer_fwd(const cwlt_encoder_layer* a, void* stream) {
                                             at(a->saved, s.x1), (float*)at(a->saved, s.mean1), (float*)at(a->saved, s.rstd1), R,
                                             D, a->ln_eps, a->p_drop, a->seed[0], a->seed_base, CWLT_BF16, stream));
     // g = dropout(gelu(linear1(x1))) and the backward's factor gd, one kernel
-    CWLT_TRY(cwlt_gemm_nt_bias_gelu_dropout(at(a->saved, s.x1), a->w1, a->b1, at(a->saved, s.g), at(a->saved, s.gd), R, F, D,
-                                            D, D, a->p_drop, a->seed[1], a->seed_base, stream));
+    // (below 256 rows on the split-K small tiles: a 128 x 256 tile leaves 8 workgroups with a 16-step chain each)
+    if (R < 256) {
+        CWLT_TRY(cwlt_gemm_bf16_small_gelu(at(a->saved, s.x1), a->w1, a->b1, at(a->saved, s.g),
+                                           a->want_backward ? at(a->saved, s.gd) : nullptr, R, F, D, D, D, a->p_drop,
+                                           a->seed[1], a->seed_base, stream));
+    } else {
+        CWLT_TRY(cwlt_gemm_nt_bias_gelu_dropout(at(a->saved, s.x1), a->w1, a->b1, at(a->saved, s.g), at(a->saved, s.gd), R, F,
+                                                D, D, D, a->p_drop, a->seed[1], a->seed_base, stream));
+    }
     // y = norm2(x1 + dropout(linear2(g)))
     CWLT_TRY(cwlt_gemm_bf16_small(at(a->saved, s.g), a->w2, a->b2, at(a->scratch, f.o), R, D, F, F, F, D, 0, stream));
     CWLT_TRY(cwlt_add_dropout_layernorm_fwd(at(a->saved, s.x1), at(a->scratch, f.o), a->gamma2, a->beta2, at(a->saved, s.s2),

@@ -126,7 +126,9 @@ class _EncoderLayerFn(torch.autograd.Function):
         # kernel (ops.ffn1_gelu_dropout), the pre-activation never reaches HBM.
         fused_ffn = (FUSED_FFN_BWD and adt == torch.bfloat16 and will_backward
                      and D % 64 == 0 and w1_a.shape[0] % 256 == 0)
-        if fused_ffn and FUSED_FFN_FWD and ops.ffn1_fused_supported(x1, w1_a, b1f):
+        if fused_ffn and small and R < 256:
+            g, h = ops.gemm_bf16_small_gelu(x1, w1_a, b1f, p, seeds[1])   # what the one-call layer runs below 256 rows
+        elif fused_ffn and FUSED_FFN_FWD and ops.ffn1_fused_supported(x1, w1_a, b1f):
             g, h = ops.ffn1_gelu_dropout(x1, w1_a, b1f, p, seeds[1])      # h holds gd
         else:
             h = (ops.gemm_bf16_small(x1, w1_a) if small

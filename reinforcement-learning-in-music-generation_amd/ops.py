@@ -739,6 +739,20 @@ def gemm_bf16_small(a, w, bias=None, out=None, accumulate=False):
     return out
 
 
+def gemm_bf16_small_gelu(x, w, bias, p=0.0, seed=0, want_gd=True):
+    """`ffn1_gelu_dropout` on the split-K small tiles (csrc/gemm_small.hip), for passes of a few hundred rows at most:
+    g = dropout(gelu(x @ w.T + bias)) [, gd = mask / (1 - p) * gelu'(.)] -- bit for bit what `gemm_bf16_small` followed by
+    `gelu_fwd(..., gd_inplace=True)` produce.  K % 128 == 0."""
+    _lib.load()
+    M, K = x.shape
+    N = w.shape[0]
+    g = torch.empty((M, N), dtype=x.dtype, device=x.device)
+    gd = torch.empty((M, N), dtype=x.dtype, device=x.device) if want_gd else None
+    _call("cwlt_gemm_bf16_small_gelu", _lib.dev(x, "x"), _lib.dev(w, "w"), _lib.dev(bias), _lib.dev(g), _lib.opt(gd), M, N, K,
+          x.stride(0), w.stride(0), float(p), int(seed), _seed_base(), _lib.stream_ptr(), work=2.0 * M * N * K)
+    return g, gd
+
+
 # --------------------------------------------------------------------------------------------------
 # one encoder layer per host call (csrc/layer.hip): steps of a few thousand token rows are bound by the HOST when every
 # kernel is its own Python-level call (the reference's RL updates: 30 windows x 50 tokens, ~970 launches)

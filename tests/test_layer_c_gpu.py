@@ -70,6 +70,30 @@ def test_gemm_small_strided_and_untouched_neighbours(cuda):
     assert lib.cwlt_gemm_bf16_small(p(ad), p(wd), None, p(big), M, 12, K, K + 24, K + 8, N + 16, 0, None) == 1001   # N % 8
 
 
+@pytest.mark.parametrize("M", [1, 50, 255])
+@pytest.mark.parametrize("p", [0.0, 0.1])
+def test_small_ffn_forward_equals_the_two_kernel_chain_bit_for_bit(cuda, M, p):
+    """cwlt_gemm_bf16_small_gelu (linear1 + bias + GELU + dropout, and the backward's factor gd, on the split-K small tiles)
+    against cwlt_gemm_bf16_small followed by cwlt_bias_gelu_dropout_fwd: the same rounded product, the same dropout
+    stream -- and against the f64 GELU of that product where nothing is dropped."""
+    a, w, bias, _ = _operands(M, 2048, 512, 31 * M + 7)
+    ad, wd, bd = a.to(cuda), w.to(cuda), bias.to(cuda)
+    g, gd = ops.gemm_bf16_small_gelu(ad, wd, bd, p, 1234)
+    h = ops.gemm_bf16_small(ad, wd)
+    hd = h.double().cpu()
+    g_ref = ops.gelu_fwd(h, bd, p, 1234, gd_inplace=True)       # h now holds gd
+    assert torch.equal(g, g_ref) and torch.equal(gd, h)
+    g_only, none = ops.gemm_bf16_small_gelu(ad, wd, bd, p, 1234, want_gd=False)
+    assert none is None and torch.equal(g_only, g)
+    x = hd + bias.double()
+    exact = 0.5 * x * (1.0 + torch.erf(x / 2.0 ** 0.5)) / (1.0 - p)
+    kept = (g != 0).cpu() | (exact.abs() < 1e-3)
+    assert ((g.double().cpu() - exact).abs()[kept] <= 2.0 ** -7 * exact.abs().clamp(min=1.0)[kept]).all()
+    if p > 0:
+        frac = 1.0 - (g != 0).float().mean().item()
+        assert M < 50 or abs(frac - p) < 0.02, frac
+
+
 def test_transpose_many(cuda):
     g = torch.Generator().manual_seed(3)
     mats = [torch.randn(r, c, generator=g).bfloat16().to(cuda) for r, c in ((1536, 512), (512, 512), (2048, 512),
