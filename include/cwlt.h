@@ -425,6 +425,10 @@ int cwlt_sample_categorical(const float* logits, const int* n_class, const float
 int cwlt_gemm_bf16_small(const void* a, const void* w, const float* bias, void* c, int64_t M, int N, int K, int64_t lda,
                          int64_t ldw, int64_t ldc, int accumulate, void* stream);
 int cwlt_transpose_bf16_many(const void* src, void* dst, const int64_t* table, int n, void* stream);
+/* dst_i = bf16(src_i) for the n arrays of `table` (DEVICE memory, n x 3 int64: element offset from src (f32), element
+ * offset from dst (bf16), element count) in one launch: the bf16 copies of an encoder's master weights, refreshed once per
+ * forward (torch's multi-tensor copy takes four launches and half the bandwidth for the same 84 tensors). */
+int cwlt_cast_bf16_many(const float* src, void* dst, const int64_t* table, int n, void* stream);
 /* cwlt_gemm_nt_bias_gelu_dropout on the split-K small tiles, for passes of a few hundred rows at most (a 50-token rollout
  * step): g = dropout_p(gelu(bf16(a . w^T) + bias)), and gd = mask / (1 - p) * gelu'(.) when gd != NULL -- what
  * cwlt_gemm_bf16_small followed by cwlt_bias_gelu_dropout_fwd produce, bit for bit (same rounding of the product, same

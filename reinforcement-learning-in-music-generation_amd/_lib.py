@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -88,6 +88,7 @@ _SIGNATURES = {
     "cwlt_gemm_bf16_tune": [_c_int, _ptr],
     "cwlt_gemm_bf16_small": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_i64, _c_int, _ptr],
     "cwlt_transpose_bf16_many": [_ptr, _ptr, _ptr, _c_int, _ptr],
+    "cwlt_cast_bf16_many": [_ptr, _ptr, _ptr, _c_int, _ptr],
     "cwlt_gemm_bf16_small_gelu": [_ptr, _ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_f32, _c_u64, _ptr,
                                   _ptr],
     "cwlt_encoder_layer_plan": [_c_i64, _c_i64, _c_int, _c_int, _c_int, _c_f32, _c_int, ctypes.POINTER(EncoderLayerPlan)],

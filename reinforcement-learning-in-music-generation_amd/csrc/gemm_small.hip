@@ -363,10 +363,40 @@ __global__ __launch_bounds__(256) void transpose_many_kernel(const bf16_t* __res
     }
 }
 
+// dst_i[0 .. n_i) = bf16(src_i[0 .. n_i)) for every entry of a table: int64 triples (source element offset from `src`,
+// destination element offset from `dst`, n) in device memory.  blockIdx.y = entry, the blocks of a row stride over it.
+__global__ __launch_bounds__(256) void cast_many_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst,
+                                                        const int64_t* __restrict__ table) {
+    const int64_t* e = table + 3 * blockIdx.y;
+    const float* s = src + e[0];
+    bf16_t* d = dst + e[1];
+    const long n = e[2];
+    const bool vec = ((((uintptr_t)s) & 15) == 0) && ((((uintptr_t)d) & 15) == 0);
+    const long n8 = vec ? n / 8 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float x[8];
+        load8(s + 8 * i, x);
+        store8(d + 8 * i, x);
+    }
+    for (long i = 8 * n8 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) d[i] = f32_to_bf16(s[i]);
+}
+
 }  // namespace gs
 }  // namespace cwlt
 
 extern "C" {
+
+/* dst_i = bf16(src_i), element by element, for the n arrays of `table` (DEVICE memory, n x 3 int64: source element offset
+ * from src (f32), destination element offset from dst (bf16), element count) in one launch. */
+int cwlt_cast_bf16_many(const float* src, void* dst, const int64_t* table, int n, void* stream) {
+    using namespace cwlt;
+    if (n < 0 || n > 65535) return CWLT_ERR_ARG;
+    if (n == 0) return CWLT_OK;
+    if (!src || !dst || !table) return CWLT_ERR_ARG;
+    hipLaunchKernelGGL(gs::cast_many_kernel, dim3(48, (unsigned)n), dim3(256), 0, (hipStream_t)stream, src, (bf16_t*)dst,
+                       table);
+    return (int)hipGetLastError();
+}
 
 /* c (M, N) [+]= a (M, K) . w (N, K)^T [+ bias (N) f32] for few rows (see include/cwlt.h): bf16 operands and result, f32
  * accumulation.  N % 8 == 0, K % 32 == 0, row strides multiples of 8 elements, 16-byte aligned pointers. */

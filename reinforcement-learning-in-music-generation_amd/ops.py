@@ -430,6 +430,10 @@ def _no_shadow():
     return None
 
 
+# CWLT_CAST_MANY=0: refresh the bf16 weight copies with torch's multi-tensor copy instead of cwlt_cast_bf16_many
+CAST_MANY = os.environ.get("CWLT_CAST_MANY", "1") != "0"
+
+
 class ShadowSet:
     """`groups`: tuples of parameters; group i becomes ONE buffer of `dtype` with its members stacked along dim 0
     (a single-member group is a plain cast).  `refresh()` -> list of buffers, up to date with the parameters."""
@@ -448,6 +452,29 @@ class ShadowSet:
                 o += p.shape[0]
             self.bufs.append(buf)
         self.fresh_in = -1           # id of the frozen_weights scope the buffers were last refreshed in
+        self._fast = None            # (parameter addresses, device table or None): the one-launch cast, see _cast_table
+
+    def _cast_table(self):
+        """bf16 copies of dense f32 GPU parameters: (table, source base, destination base, n) for cwlt_cast_bf16_many --
+        one launch where torch's multi-tensor copy takes four for the 84 tensors of an encoder -- or None (other dtypes,
+        or parameters that moved while a capture is running: the multi-tensor copy then).  Rebuilt when a parameter's
+        storage moves."""
+        ptrs = tuple(p.data_ptr() for p in self.src)
+        if self._fast is None or self._fast[0] != ptrs:
+            ok = (self.dtype == torch.bfloat16 and self.device.type == "cuda"
+                  and all(p.dtype == torch.float32 and p.is_contiguous() for p in self.src)
+                  and all(d.is_contiguous() for d in self.dst))
+            if ok and torch.cuda.is_current_stream_capturing():
+                return None                                  # the table is a host-to-device copy: not inside a capture
+            entry = None
+            if ok:
+                sbase = min(ptrs)
+                dbase = min(d.data_ptr() for d in self.dst)
+                rows = [((p.data_ptr() - sbase) // 4, (d.data_ptr() - dbase) // 2, p.numel())
+                        for p, d in zip(self.src, self.dst)]
+                entry = (torch.tensor(rows, dtype=torch.int64).to(self.device), sbase, dbase, len(rows))
+            self._fast = (ptrs, entry)
+        return self._fast[1]
 
     def matches(self, dtype, device):
         return self.dtype == dtype and self.device == device and all(p.device == device for p in self.src)
@@ -462,8 +489,14 @@ class ShadowSet:
         if scope and self.fresh_in == scope and not (self.device.type == "cuda"
                                                      and torch.cuda.is_current_stream_capturing()):
             return self.bufs
-        with torch.no_grad():
-            torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
+        fast = self._cast_table() if CAST_MANY else None
+        if fast is not None:
+            table, sbase, dbase, n = fast
+            _call("cwlt_cast_bf16_many", ctypes.c_void_p(sbase), ctypes.c_void_p(dbase), _lib.dev(table), n,
+                  _lib.stream_ptr())
+        else:
+            with torch.no_grad():
+                torch._foreach_copy_(self.dst, [p.detach() for p in self.src])
         self.fresh_in = scope if scope else -1
         return self.bufs
 

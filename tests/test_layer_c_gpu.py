@@ -105,6 +105,28 @@ def test_transpose_many(cuda):
         assert torch.equal(v, m.t())
 
 
+def test_cast_many_equals_the_multi_tensor_copy(cuda, monkeypatch):
+    """ops.ShadowSet's one-launch refresh (cwlt_cast_bf16_many) against torch._foreach_copy_: the same bf16 values, odd
+    sizes and unaligned slices included; follows a parameter whose storage moved."""
+    g = torch.Generator().manual_seed(2)
+    ps = [torch.nn.Parameter(torch.randn(sh, generator=g).to(cuda)) for sh in ((512, 512), (1536,), (7, 3), (2048, 512), (5,),
+                                                                                (513,), (1, 1))]
+    groups = [(ps[0],), (ps[1],), (ps[2], ps[2]), (ps[3],), (ps[4], ps[5], ps[4]), (ps[6],)]
+    fast = ops.ShadowSet(groups, torch.bfloat16)
+    bufs = [b.clone() for b in fast.refresh()]
+    assert fast._fast[1] is not None                            # the one-launch path was taken
+    monkeypatch.setattr(ops, "CAST_MANY", False)
+    slow = ops.ShadowSet(groups, torch.bfloat16)
+    for a, b in zip(bufs, slow.refresh()):
+        assert torch.equal(a, b)
+    monkeypatch.setattr(ops, "CAST_MANY", True)
+    with torch.no_grad():
+        ps[3].data = torch.randn(2048, 512, generator=g).to(cuda)   # new storage
+        ps[0].mul_(2.0)
+    got = fast.refresh()
+    assert torch.equal(got[3], ps[3].detach().bfloat16()) and torch.equal(got[0], ps[0].detach().bfloat16())
+
+
 def _encoder(cuda, n_layers, p, seed):
     enc = encoder.TransformerEncoderBuilder.from_kwargs(
         n_layers=n_layers, n_heads=8, query_dimensions=64, value_dimensions=64, feed_forward_dimensions=2048,
