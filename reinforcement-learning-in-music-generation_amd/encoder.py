@@ -69,7 +69,8 @@ class _EncoderLayerFn(torch.autograd.Function):
             bo_a, b2_a = bo.to(adt), b2.to(adt)
         g1f, be1f, g2f, be2f, b1f = (ops._f32(t) for t in (g1, be1, g2, be2, b1))
 
-        if shadow is not None and len(shadow) > 8:
+        ctx.wt = shadow[10] if shadow is not None and len(shadow) > 10 else None
+        if shadow is not None and len(shadow) > 8 and shadow[8] is not None:
             # steps of a few thousand token rows: the whole layer is ONE host call (csrc/layer.hip) -- the same kernels,
             # enqueued from C; what the backward needs stays in one `saved` buffer
             cache, li = shadow[8], shadow[9]
@@ -202,36 +203,43 @@ class _EncoderLayerFn(torch.autograd.Function):
         # `out` = the residual gradient the product is added onto
         small = ops.gemm_small_per_op(dout2)
 
-        def dgrad(g_, w_, out=None):
+        # the transposed copies: refreshed for all layers by ONE launch per forward when the encoder passed them
+        # (ops.LayerCache.refresh_transposed), else made here (a 0.5-2 MB copy kernel per use)
+        wt = ctx.wt
+
+        def tr(w_, j):
+            return wt[j] if wt is not None else w_.t().contiguous()
+
+        def dgrad(g_, w_, j, out=None):
             if small:
-                return ops.gemm_bf16_small(g_, w_.t().contiguous(), out=out, accumulate=out is not None)
+                return ops.gemm_bf16_small(g_, tr(w_, j), out=out, accumulate=out is not None)
             if ops.gemm_bf16_supported(g_, w_.t(), out, transposed_w=True):
-                return ops.gemm_bf16(g_, w_.t().contiguous(), out=out, accumulate=out is not None)
+                return ops.gemm_bf16(g_, tr(w_, j), out=out, accumulate=out is not None)
             if out is not None:
-                return out.addmm_(g_, w_.t().contiguous().t() if nt else w_)
-            return torch.mm(g_, w_.t().contiguous().t()) if nt else torch.mm(g_, w_)
+                return out.addmm_(g_, tr(w_, j).t() if nt else w_)
+            return torch.mm(g_, tr(w_, j).t()) if nt else torch.mm(g_, w_)
 
         dw2 = wgrad(dy, g)                                                 # (D, F)
         if ctx.fused_ffn:
             # h holds gd (see forward): input gradient of linear2, activation + dropout backward and linear1's bias
             # gradient in ONE kernel; dgact (R x F) never reaches memory
-            dh, db1 = ops.gemm_nt_mul(dy, w2_a.t().contiguous(), h)
+            dh, db1 = ops.gemm_nt_mul(dy, tr(w2_a, 3), h)
         else:
-            dgact = dgrad(dy, w2_a)                                        # (R, F)
+            dgact = dgrad(dy, w2_a, 3)                                        # (R, F)
             dh, db1 = ops.gelu_bwd(dgact, h, b1f, p, seeds[1])
             del dgact
         if DX1_IN_PLACE:
             # linear1's input gradient lands ON the residual gradient (C = D = ds2, beta = 1): norm1's backward then
             # reads one gradient stream instead of two, and the extra read sits in a GEMM that has HBM time to spare.
             # dy may alias ds2 (p = 0); its last readers (dw2, dh) are already enqueued.
-            dgrad(dh, w1_a, out=ds2)                                       # (R, D)
+            dgrad(dh, w1_a, 2, out=ds2)                                       # (R, D)
             dx1 = None
         else:
-            dx1 = dgrad(dh, w1_a)                                          # (R, D)
+            dx1 = dgrad(dh, w1_a, 2)                                          # (R, D)
         dw1 = wgrad(dh, x1)                                                # (F, D)
         del dh
         ds1, do, dg1, dbe1, dbo = ops.ln_bwd(ds2, dx1, s1, g1f, mean1, rstd1, p, seeds[0])
-        da = dgrad(do, wo_a)                                               # (R, D)
+        da = dgrad(do, wo_a, 1)                                               # (R, D)
         dwo = wgrad(do, a.view(R, D))
         qkv5 = qkv.view(N, L, 3, H, D // H)
         dqkv, dbqkv = ops.cla_bwd(qkv5[:, :, 0], qkv5[:, :, 1], qkv5[:, :, 2], a, zinv, da.view(N, L, H, D // H),
@@ -239,9 +247,9 @@ class _EncoderLayerFn(torch.autograd.Function):
         ctx.fin = None
         dqkv2 = dqkv.view(R, 3 * D)
         if small:
-            dx = ops.gemm_bf16_small(dqkv2, wqkv.t().contiguous(), out=ds1, accumulate=True)
+            dx = ops.gemm_bf16_small(dqkv2, tr(wqkv, 0), out=ds1, accumulate=True)
         elif ops.gemm_bf16_supported(dqkv2, wqkv.t(), ds1, transposed_w=True):
-            dx = ops.gemm_bf16(dqkv2, wqkv.t().contiguous(), out=ds1, accumulate=True)
+            dx = ops.gemm_bf16(dqkv2, tr(wqkv, 0), out=ds1, accumulate=True)
         else:
             dx = ds1.addmm_(dqkv2, wqkv)                                   # residual + projection gradient, in place
                                                                            # (NN is hipBLASLt's faster form for this shape)
@@ -414,6 +422,7 @@ class TransformerEncoder(nn.Module):
         self._shadow = None                                  # ops.ShadowSet of the layers' compute-dtype weights
         self._shadow32 = None                                # ... and of the stacked Q/K/V biases in f32 (bf16 mode)
         self._cache = None                                   # ops.LayerCache of the one-call layers (few token rows)
+        self._tcache = None                                  # ops.LayerCache holding the transposed weights (training sizes)
 
     def _layer_c_ok(self, x):
         """Whether this forward runs its layers as one host call each (csrc/layer.hip): bf16, at most
@@ -468,10 +477,22 @@ class TransformerEncoder(nn.Module):
                                   (x.shape[2], self.layers[0].linear1.weight.shape[0], self.layers[0].attention.n_heads))
             x = _EncoderStackFn.apply(x, self, cache, torch.is_grad_enabled(), *cache.params)
         else:
+            tcache = None
+            if (cache is None and ops.DGRAD_WT_CACHE and x.dtype == torch.bfloat16 and torch.is_grad_enabled()
+                    and x.shape[0] * x.shape[1] >= 16384):
+                # training sizes: the input-gradient products run on transposed weight copies (encoder._EncoderLayerFn
+                # backward); all 48 of them by one launch here instead of a copy kernel per use there
+                tcache = self._tcache
+                if tcache is None or tcache.owner is not sh:
+                    tcache = self._tcache = ops.LayerCache([bufs[per * i + j] for i in range(len(self.layers))
+                                                            for j in (0, 2, 4, 5)], sh)
+                tcache.refresh_transposed()
             for i, layer in enumerate(self.layers):
                 sh_i = tuple(bufs[per * i:per * (i + 1)])
                 if cache is not None:
                     sh_i = sh_i + (bufs32[i], cache, i)
+                elif tcache is not None:
+                    sh_i = sh_i + (bufs32[i] if bufs32 is not None else None, None, i, tuple(tcache.views[4 * i:4 * i + 4]))
                 elif bufs32 is not None:
                     sh_i = sh_i + (bufs32[i],)
                 x = layer(x, attn_mask, sh_i)

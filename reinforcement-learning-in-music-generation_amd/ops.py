@@ -430,6 +430,8 @@ def _no_shadow():
     return None
 
 
+# CWLT_DGRAD_WT_CACHE=0: the per-op layer transposes a weight at every use in the backward instead of once per forward
+DGRAD_WT_CACHE = os.environ.get("CWLT_DGRAD_WT_CACHE", "1") != "0"
 # CWLT_CAST_MANY=0: refresh the bf16 weight copies with torch's multi-tensor copy instead of cwlt_cast_bf16_many
 CAST_MANY = os.environ.get("CWLT_CAST_MANY", "1") != "0"
 

@@ -240,3 +240,22 @@ def test_plan_and_refusals(cuda):
     st = _lib.EncoderLayer(n_seq=30, len=50, d_model=512, d_ff=2048, n_heads=8, want_backward=1, p_drop=0.1)
     assert lib.cwlt_encoder_layer_fwd(ctypes.byref(st), None) == 1001                                  # null pointers
     assert lib.cwlt_encoder_layer_bwd(ctypes.byref(st), None) == 1001
+
+
+def test_transposed_weights_once_per_forward_equal_the_per_use_copies(cuda, monkeypatch):
+    """Training sizes (per-op layer, >= 16 384 token rows): the input-gradient products read transposed weight copies made
+    by ONE launch per forward (ops.LayerCache.refresh_transposed) instead of a copy kernel per use: same bytes, so the
+    same results bit for bit."""
+    enc = _encoder(cuda, 2, 0.1, seed=9)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(16, 1024, 512, generator=g).bfloat16().to(cuda)
+    dy = (torch.randn(16, 1024, 512, generator=g) * 0.1).bfloat16().to(cuda)
+    monkeypatch.setattr(ops, "DGRAD_WT_CACHE", True)
+    ya, dxa, ga = _run(enc, x, dy, "lib", monkeypatch)
+    assert enc._tcache is not None
+    monkeypatch.setattr(ops, "DGRAD_WT_CACHE", False)
+    yb, dxb, gb = _run(enc, x, dy, "lib", monkeypatch)
+    assert torch.equal(ya, yb) and torch.equal(dxa, dxb)
+    for n in gb:
+        assert torch.equal(ga[n], gb[n]), n
+
