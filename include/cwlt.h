@@ -342,6 +342,14 @@ int cwlt_wgrad_splits(int64_t M, int N1, int N2);
 int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64_t M, int N1, int N2,
                     int64_t lda, int64_t ldb, int accumulate, void* stream);
 
+/* Up to four such products over the SAME M token rows in one launch + one reduce launch: the four weight gradients of an
+ * encoder layer at few token rows run 20-80 workgroups each, 240 together.  All arrays are HOST arrays of `count` (1..4)
+ * entries; widths multiples of 256; part[p]: cwlt_wgrad_splits(M, n1[p], n2[p]) * n1[p] * n2[p] floats, distinct buffers.
+ * Results bit-identical to count calls of cwlt_wgrad_bf16 (every product cuts the rows as its own launch would). */
+int cwlt_wgrad_bf16_group(const void* const* a, const void* const* b, float* const* part, float* const* out, const int* n1,
+                          const int* n2, const int64_t* lda, const int64_t* ldb, int count, int64_t M, int accumulate,
+                          void* stream);
+
 /* ---- recurrent (generation) form of the causal linear attention ------------------------------------
  * One token: Zi += phi(k); Si += phi(k) (x) v; out = (phi(q) . Si) / (phi(q) . Zi + eps), state updated in
  * place.  Replaces fast_transformers RecurrentLinearAttention.forward as built by RecurrentEncoderBuilder at

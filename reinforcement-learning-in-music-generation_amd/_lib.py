@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(_PKG, "libcwlt.so")
 
 CWLT_F32 = 0
 CWLT_BF16 = 1
-ABI_VERSION = 19
+ABI_VERSION = 20
 
 _c_int = ctypes.c_int
 _c_i64 = ctypes.c_int64
@@ -109,6 +109,7 @@ _SIGNATURES = {
     "cwlt_band_attn_bwd": [_ptr] * 10 + [_c_int] * 5 + [_c_i64] * 8 + [_c_f32, _c_f32, _c_u64, _ptr, _c_int, _ptr],
     "cwlt_wgrad_splits": [_c_i64, _c_int, _c_int],
     "cwlt_wgrad_bf16": [_ptr, _ptr, _ptr, _ptr, _c_i64, _c_int, _c_int, _c_i64, _c_i64, _c_int, _ptr],
+    "cwlt_wgrad_bf16_group": [_ptr] * 8 + [_c_int, _c_i64, _c_int, _ptr],
     "cwlt_recurrent_cla_step": [_ptr] * 6 + [_c_int] * 3 + [_c_i64] * 4 + [_c_f32, _c_int, _ptr],
     "cwlt_decode_workspace_floats": [ctypes.POINTER(DecodeModel)],
     "cwlt_decode_step": [ctypes.POINTER(DecodeModel), _ptr, _ptr, _ptr, _ptr, _c_int, _ptr],

@@ -10,6 +10,8 @@
 // reuses one scratch buffer.  Sizes and offsets: cwlt_encoder_layer_plan.  The plain projections go through
 // cwlt_gemm_bf16_small (64 x 64 tiles): this path is for steps of a few thousand token rows; the per-op path with
 // gemm_bf16.hip's 256 x 256 tiles keeps the training sizes.
+#include <stdlib.h>
+
 #include "cwlt_common.h"
 #include "cwlt.h"
 
@@ -34,6 +36,7 @@ struct FwdScratch {
 };
 struct BwdScratch {
     int64_t ds2, dyl, dh, dox, dattn, dqkv, lnpart, wpart, mpart, cs, ws, dden, total;
+    int64_t wp[4];             // the four weight gradients' partial-tile buffers (linear2, linear1, out, qkv), each inside wpart
 };
 
 bool dims_ok(const Dims& d) {
@@ -107,9 +110,20 @@ BwdScratch plan_bwd(const Dims& d) {
     s.dattn = o; o += up(RD);
     s.dqkv = o; o += up(3 * RD);
     s.lnpart = o; o += up((int64_t)cwlt_ln_blocks(d.R) * 3 * D * 4);
-    const int64_t wp = max4((int64_t)cwlt_wgrad_splits(d.R, D, F) * D * F, (int64_t)cwlt_wgrad_splits(d.R, F, D) * F * D,
-                            (int64_t)cwlt_wgrad_splits(d.R, D, D) * D * D, (int64_t)cwlt_wgrad_splits(d.R, 3 * D, D) * 3 * D * D);
-    s.wpart = o; o += up(wp * 4);
+    // the four weight gradients run as ONE grouped launch when their operands all survive to the end of the layer (dropout
+    // on: the masked gradients are buffers of their own): four partial-tile buffers side by side; else one, reused
+    const int64_t w4[4] = {(int64_t)cwlt_wgrad_splits(d.R, D, F) * D * F, (int64_t)cwlt_wgrad_splits(d.R, F, D) * F * D,
+                           (int64_t)cwlt_wgrad_splits(d.R, D, D) * D * D, (int64_t)cwlt_wgrad_splits(d.R, 3 * D, D) * 3 * D * D};
+    s.wpart = o;
+    if (d.drop) {
+        for (int i = 0; i < 4; ++i) {
+            s.wp[i] = o;
+            o += up(w4[i] * 4);
+        }
+    } else {
+        for (int i = 0; i < 4; ++i) s.wp[i] = o;
+        o += up(max4(w4[0], w4[1], w4[2], w4[3]) * 4);
+    }
     s.mpart = o; o += up(cwlt_gemm_nt_tiles(d.R) * F * 4);
     s.cs = o; o += up(3 * d.N * d.P * D * 4);
     s.ws = o; o += up(!d.fin && d.P > 1 ? cwlt_scan_seg_floats((int)d.N, d.H, d.P, 1) * 4 : 0);
@@ -148,6 +162,12 @@ __global__ void qkv_bias_sum_kernel(const float* __restrict__ cs, float* __restr
     float s = 0.f;
     for (int b = 0; b < nb; ++b) s += p[(long)b * HD];
     out[i] = s;
+}
+
+// CWLT_LAYER_GROUP_WGRAD=0: four separate weight-gradient launches per layer backward (A/B)
+inline bool group_wgrads() {
+    static const bool on = [] { const char* e = getenv("CWLT_LAYER_GROUP_WGRAD"); return !(e && e[0] == '0'); }();
+    return on;
 }
 
 inline char* at(void* base, int64_t off) { return (char*)base + off; }
@@ -239,7 +259,7 @@ int cwlt_encoder_layer_bwd(const cwlt_encoder_layer* a, void* stream) {
     const int D = d.D, F = d.F, H = d.H;
     const int64_t R = d.R;
     hipStream_t st = (hipStream_t)stream;
-    float* wpart = (float*)at(a->scratch, b.wpart);
+    const bool grouped = d.drop && group_wgrads();
     float* lnpart = (float*)at(a->scratch, b.lnpart);
     char* ds2 = at(a->scratch, b.ds2);
     char* dyl = d.drop ? at(a->scratch, b.dyl) : ds2;          // gradient of linear2's output (= ds2 without dropout)
@@ -253,19 +273,25 @@ int cwlt_encoder_layer_bwd(const cwlt_encoder_layer* a, void* stream) {
                                             (const float*)at(a->saved, s.rstd2), ds2, d.drop ? dyl : nullptr, lnpart,
                                             a->grads + g.ln2, R, D, a->p_drop, a->seed[2], a->seed_base, CWLT_BF16, stream));
     // linear2: weight gradient; input gradient x activation gradient (+ linear1's bias gradient) in one kernel
-    CWLT_TRY(cwlt_wgrad_bf16(dyl, at(a->saved, s.g), wpart, a->grads + g.w2, R, D, F, D, F, 0, stream));
+    if (!grouped)
+        CWLT_TRY(cwlt_wgrad_bf16(dyl, at(a->saved, s.g), (float*)at(a->scratch, b.wp[0]), a->grads + g.w2, R, D, F, D, F, 0,
+                                 stream));
     CWLT_TRY(cwlt_gemm_nt_mul(dyl, a->w2_t, at(a->saved, s.gd), dh, (float*)at(a->scratch, b.mpart), a->grads + g.b1, R, F, D, D,
                               D, F, F, stream));
     // linear1: input gradient lands ON the residual gradient; weight gradient
     CWLT_TRY(cwlt_gemm_bf16_small(dh, a->w1_t, nullptr, ds2, R, D, F, F, F, D, 1, stream));
-    CWLT_TRY(cwlt_wgrad_bf16(dh, at(a->saved, s.x1), wpart, a->grads + g.w1, R, F, D, F, D, 0, stream));
+    if (!grouped)
+        CWLT_TRY(cwlt_wgrad_bf16(dh, at(a->saved, s.x1), (float*)at(a->scratch, b.wp[1]), a->grads + g.w1, R, F, D, F, D, 0,
+                                 stream));
     // norm1 backward: dx <- residual gradient, dox, (dgamma1 | dbeta1 | dbo)
     CWLT_TRY(cwlt_add_dropout_layernorm_bwd(ds2, nullptr, at(a->saved, s.s1), a->gamma1, (const float*)at(a->saved, s.mean1),
                                             (const float*)at(a->saved, s.rstd1), a->dx, d.drop ? dox : nullptr, lnpart,
                                             a->grads + g.ln1, R, D, a->p_drop, a->seed[0], a->seed_base, CWLT_BF16, stream));
     // out-projection
     CWLT_TRY(cwlt_gemm_bf16_small(dox, a->wo_t, nullptr, dattn, R, D, D, D, D, D, 0, stream));
-    CWLT_TRY(cwlt_wgrad_bf16(dox, at(a->saved, s.a), wpart, a->grads + g.wo, R, D, D, D, D, 0, stream));
+    if (!grouped)
+        CWLT_TRY(cwlt_wgrad_bf16(dox, at(a->saved, s.a), (float*)at(a->scratch, b.wp[2]), a->grads + g.wo, R, D, D, D, D, 0,
+                                 stream));
     // causal linear attention: dq | dk | dv side by side + their column sums per sequence (the Q/K/V bias gradients)
     float* cs = (float*)at(a->scratch, b.cs);
     const int64_t csn = d.N * d.P * D;
@@ -290,7 +316,22 @@ int cwlt_encoder_layer_bwd(const cwlt_encoder_layer* a, void* stream) {
     CWLT_TRY((int)hipGetLastError());
     // Q | K | V projection: input gradient onto the residual gradient, weight gradient
     CWLT_TRY(cwlt_gemm_bf16_small(dqkv, a->wqkv_t, nullptr, a->dx, R, D, 3 * D, 3 * D, 3 * D, D, 1, stream));
-    CWLT_TRY(cwlt_wgrad_bf16(dqkv, a->x, wpart, a->grads + g.wqkv, R, 3 * D, D, 3 * D, D, 0, stream));
+    if (!grouped) {
+        CWLT_TRY(cwlt_wgrad_bf16(dqkv, a->x, (float*)at(a->scratch, b.wp[3]), a->grads + g.wqkv, R, 3 * D, D, 3 * D, D, 0,
+                                 stream));
+        return CWLT_OK;
+    }
+    // the four weight gradients of the layer in one launch + one reduce (20-80 workgroups each at 1 500 rows, 240 together;
+    // 8 launches of 12.6 + 5 us before).  Their operands are all still in place: with dropout on, the masked gradients dyl
+    // and dox are buffers of their own, not the residual gradients the input-gradient products accumulate onto.
+    const void* ga[4] = {dyl, dh, dox, dqkv};
+    const void* gb[4] = {at(a->saved, s.g), at(a->saved, s.x1), at(a->saved, s.a), a->x};
+    float* gp[4] = {(float*)at(a->scratch, b.wp[0]), (float*)at(a->scratch, b.wp[1]), (float*)at(a->scratch, b.wp[2]),
+                    (float*)at(a->scratch, b.wp[3])};
+    float* go[4] = {a->grads + g.w2, a->grads + g.w1, a->grads + g.wo, a->grads + g.wqkv};
+    const int n1[4] = {D, F, D, 3 * D}, n2[4] = {F, D, D, D};
+    const int64_t la[4] = {D, F, D, 3 * D}, lb[4] = {F, D, D, D};
+    CWLT_TRY(cwlt_wgrad_bf16_group(ga, gb, gp, go, n1, n2, la, lb, 4, R, 0, stream));
     return CWLT_OK;
 }
 

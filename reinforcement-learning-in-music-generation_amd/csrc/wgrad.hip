@@ -52,10 +52,12 @@ __device__ __forceinline__ bf16x8 tfrag_at(const char* base) {
     return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 
-template <bool EDGE, bool ILV = true>
-__global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                      float* __restrict__ part, long M, int N1, int N2, long lda,
-                                                      long ldb, long mslice) {
+// The kernel proper, as a function of the workgroup's index `id` among the ntile * S workgroups of ONE product: the plain
+// kernel passes blockIdx.x, the grouped kernel (several products in one launch) the index inside the product it belongs to.
+template <bool EDGE, bool ILV>
+__device__ __forceinline__ void wgrad_body(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                           float* __restrict__ part, long M, int N1, int N2, long lda, long ldb,
+                                           long mslice, const int id, const int S) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // NSTAGE x [A stage | B stage]
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -67,8 +69,6 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     // XCD lets those re-reads hit that XCD's L2 instead of HBM (used when the number of slices S is a multiple of 8).
     const int nt1 = (N1 + TM - 1) / TM, nt2 = (N2 + TN - 1) / TN;   // partial edge tiles allowed (N % 8 == 0)
     const int ntile = nt1 * nt2;
-    const int id = blockIdx.x;
-    const int S = gridDim.x / ntile;                // the launcher's grid is exactly ntile * S workgroups
     int slice, tile;
     if (S & 7) {                                    // few token rows -> few slices: plain (slice, tile) order
         slice = id / ntile;
@@ -249,6 +249,62 @@ __global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ 
     }
 }
 
+template <bool EDGE, bool ILV = true>
+__global__ __launch_bounds__(1024) void wgrad_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                      float* __restrict__ part, long M, int N1, int N2, long lda,
+                                                      long ldb, long mslice) {
+    const int ntile = ((N1 + TM - 1) / TM) * ((N2 + TN - 1) / TN);
+    wgrad_body<EDGE, ILV>(A, B, part, M, N1, N2, lda, ldb, mslice, (int)blockIdx.x,
+                          (int)(gridDim.x / ntile));       // the launcher's grid is exactly ntile * S workgroups
+}
+
+// Up to four products over the SAME token rows in one launch (the four weight gradients of an encoder layer at few token
+// rows: 20-80 workgroups each, 240 together): workgroup ids [start[p], start[p + 1]) belong to product p.  Widths are
+// multiples of 256 (no edge tiles).
+struct WgGroup {
+    const bf16_t* a[4];
+    const bf16_t* b[4];
+    float* part[4];
+    float* out[4];
+    int n1[4], n2[4], S[4];
+    long lda[4], ldb[4], mslice[4];
+    int start[5];               // workgroup ranges of the products; start[count] = grid size
+    long rstart[5];             // float4 ranges of the reduce launch
+    int count;
+};
+template <bool ILV>
+__global__ __launch_bounds__(1024) void wgrad_group_kernel(const WgGroup g, long M) {
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.count && (int)blockIdx.x >= g.start[i]) p = i;
+    wgrad_body<false, ILV>(g.a[p], g.b[p], g.part[p], M, g.n1[p], g.n2[p], g.lda[p], g.ldb[p], g.mslice[p],
+                           (int)blockIdx.x - g.start[p], g.S[p]);
+}
+// the reduce of every product of a group: thread t of the launch owns float4 t - rstart[p] of product p
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const WgGroup g, int accumulate) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x;
+    int p = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.count && t >= g.rstart[i]) p = i;
+    const long n = (long)g.n1[p] * g.n2[p];
+    const long i = (t - g.rstart[p]) * 4;
+    if (t >= g.rstart[g.count] || i >= n) return;
+    const float* part = g.part[p];
+    float4 a = load4(part + i);
+    for (int s = 1; s < g.S[p]; ++s) {
+        const float4 v = load4(part + (long)s * n + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    float* out = g.out[p];
+    if (accumulate) {
+        const float4 o = load4(out + i);
+        a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+    }
+    store4(out + i, a);
+}
+
 // out[e] (+)= sum_s part[s * n + e], 4 floats per thread, fixed order
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ out,
                                                            int S, long n, int accumulate) {
@@ -344,6 +400,68 @@ int cwlt_wgrad_bf16(const void* a, const void* b, float* part, float* out, int64
     const long n = (long)N1 * N2;
     hipLaunchKernelGGL(wg::wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, part, out, S,
                        n, accumulate);
+    return (int)hipGetLastError();
+}
+
+/* count (1..4) products out_p (n1_p, n2_p) f32 (+)= A_p^T B_p over the SAME M token rows in ONE launch + one reduce launch
+ * (see include/cwlt.h).  All arrays are HOST arrays of `count` entries; widths multiples of 256; part_p:
+ * cwlt_wgrad_splits(M, n1_p, n2_p) * n1_p * n2_p floats each, distinct buffers. */
+int cwlt_wgrad_bf16_group(const void* const* a, const void* const* b, float* const* part, float* const* out, const int* n1,
+                          const int* n2, const int64_t* lda, const int64_t* ldb, int count, int64_t M, int accumulate,
+                          void* stream) {
+    using namespace cwlt;
+    if (count < 1 || count > 4 || !a || !b || !part || !out || !n1 || !n2 || !lda || !ldb || M <= 0) return CWLT_ERR_ARG;
+    wg::WgGroup g;
+    g.count = count;
+    g.start[0] = 0;
+    g.rstart[0] = 0;
+    for (int p = 0; p < 4; ++p) {
+        const int q = p < count ? p : 0;                 // unused slots repeat product 0 (never selected)
+        if (!a[q] || !b[q] || !part[q] || !out[q]) return CWLT_ERR_ARG;
+        if (n1[q] <= 0 || n2[q] <= 0 || (n1[q] & 255) || (n2[q] & 255) || (lda[q] & 7) || (ldb[q] & 7) || lda[q] < n1[q] ||
+            ldb[q] < n2[q])
+            return CWLT_ERR_ARG;
+        g.a[p] = (const bf16_t*)a[q];
+        g.b[p] = (const bf16_t*)b[q];
+        g.part[p] = part[q];
+        g.out[p] = out[q];
+        g.n1[p] = n1[q];
+        g.n2[p] = n2[q];
+        g.lda[p] = (long)lda[q];
+        g.ldb[p] = (long)ldb[q];
+        g.S[p] = cwlt_wgrad_splits(M, n1[q], n2[q]);
+        // every product cuts the rows as its own launch would (cwlt_wgrad_bf16): whole 32-row steps
+        long ms = (M + g.S[p] - 1) / g.S[p];
+        g.mslice[p] = (ms + wg::BK - 1) / wg::BK * wg::BK;
+        if (p < count) {
+            g.start[p + 1] = g.start[p] + (n1[q] / 256) * (n2[q] / 256) * g.S[p];
+            g.rstart[p + 1] = g.rstart[p] + ((long)n1[q] * n2[q] / 4 + 255) / 256 * 256;
+        }
+    }
+    for (int p = count; p < 4; ++p) {
+        g.start[p + 1] = g.start[count];
+        g.rstart[p + 1] = g.rstart[count];
+    }
+    constexpr int lds_bytes = wg::NSTAGE * 2 * wg::OPB;
+    static unsigned long long lds_set = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= 64 || !((lds_set >> dev) & 1ull)) {
+        int e = (int)hipFuncSetAttribute((const void*)wg::wgrad_group_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         lds_bytes);
+        if (!e)
+            e = (int)hipFuncSetAttribute((const void*)wg::wgrad_group_kernel<false>,
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        if (e) return e;
+        if (dev < 64) lds_set |= 1ull << dev;
+    }
+    static const bool ilv = [] { const char* e = getenv("CWLT_WGRAD_ILV"); return !(e && e[0] == '0'); }();
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ilv ? wg::wgrad_group_kernel<true> : wg::wgrad_group_kernel<false>, dim3((unsigned)g.start[count]),
+                       dim3(1024), lds_bytes, st, g, (long)M);
+    int e = (int)hipGetLastError();
+    if (e) return e;
+    hipLaunchKernelGGL(wg::wgrad_reduce_group_kernel, dim3((unsigned)(g.rstart[count] / 256)), dim3(256), 0, st, g, accumulate);
     return (int)hipGetLastError();
 }
 

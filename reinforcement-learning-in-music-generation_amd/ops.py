@@ -1030,6 +1030,26 @@ def wgrad(a, b, out=None, accumulate=False):
     return out
 
 
+def wgrad_group(pairs, accumulate=False, outs=None):
+    """[(a_i, b_i)] (at most four, all with the same number of rows, widths multiples of 256) -> [a_i^T b_i] f32, as ONE
+    launch + one reduce launch (cwlt_wgrad_bf16_group): bit-identical to `wgrad` on every pair."""
+    lib = _lib.load()
+    n = len(pairs)
+    M = pairs[0][0].shape[0]
+    parts, res = [], []
+    for i, (a, b) in enumerate(pairs):
+        N1, N2 = a.shape[1], b.shape[1]
+        parts.append(torch.empty(lib.cwlt_wgrad_splits(M, N1, N2) * N1 * N2, dtype=torch.float32, device=a.device))
+        res.append(outs[i] if outs is not None else torch.empty((N1, N2), dtype=torch.float32, device=a.device))
+    vp = ctypes.c_void_p * n
+    _call("cwlt_wgrad_bf16_group", vp(*[a.data_ptr() for a, _ in pairs]), vp(*[b.data_ptr() for _, b in pairs]),
+          vp(*[t.data_ptr() for t in parts]), vp(*[t.data_ptr() for t in res]),
+          (ctypes.c_int * n)(*[a.shape[1] for a, _ in pairs]), (ctypes.c_int * n)(*[b.shape[1] for _, b in pairs]),
+          (ctypes.c_int64 * n)(*[a.stride(0) for a, _ in pairs]), (ctypes.c_int64 * n)(*[b.stride(0) for _, b in pairs]),
+          n, M, 1 if accumulate else 0, _lib.stream_ptr())
+    return res
+
+
 class LinearWgradFn(torch.autograd.Function):
     """y = x @ w.T + b for a bf16 activation x and f32 master parameters (in_linear, the fused head projection).
     Same forward as F.linear on the bf16 casts; the backward takes the weight gradient with the split-K MFMA kernel

@@ -79,3 +79,25 @@ print("wgrad2 ok")
     env = dict(os.environ, CWLT_WGRAD_V2="1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "wgrad2 ok" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.parametrize("M", [50, 1500, 8192])
+def test_grouped_launch_equals_the_four_separate_ones(cuda, M):
+    """cwlt_wgrad_bf16_group: the four weight gradients of an encoder layer (linear2, linear1, out-projection, Q|K|V) over
+    the same token rows in ONE launch + one reduce: the same slices, the same summation order -> bit for bit the results
+    of four cwlt_wgrad_bf16 calls (M = 8 192: the products cut the rows into different numbers of slices); accumulate
+    form; fewer than four products."""
+    g = torch.Generator().manual_seed(M)
+    mk = lambda n: torch.randn(M, n, generator=g).bfloat16().to(cuda)
+    pairs = [(mk(512), mk(2048)), (mk(2048), mk(512)), (mk(512), mk(512)), (mk(1536), mk(512))]
+    one = [ops.wgrad(a, b) for a, b in pairs]
+    grp = ops.wgrad_group(pairs)
+    for x, y in zip(one, grp):
+        assert torch.equal(x, y)
+    outs = [torch.full_like(x, 0.5) for x in one]
+    ops.wgrad_group(pairs, accumulate=True, outs=outs)
+    for x, y in zip(one, outs):
+        assert torch.equal(x + 0.5, y)
+    two = ops.wgrad_group(pairs[2:])
+    assert torch.equal(two[0], one[2]) and torch.equal(two[1], one[3])
+
