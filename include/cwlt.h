@@ -448,7 +448,7 @@ int cwlt_gemm_bf16_small_gelu(const void* a, const void* w, const float* bias, v
  * built at dqn_policy/model.py:128-137 (ppo_policy/model.py:129-138) and called at :232:
  *     x1 = norm1(x + dropout(out_projection(causal_linear_attention(q, k, v))));
  *     y  = norm2(x1 + dropout(linear2(dropout(gelu(linear1(x1))))))
- * -- enqueued by ONE host call forward (8 launches) and one backward (19-21 launches), through the entry points above
+ * -- enqueued by ONE host call forward (8 launches) and one backward (13-21 launches: 13 with the four weight gradients as one grouped launch), through the entry points above
  * (same kernels, same dropout streams as the per-op path).  bf16 activations; d_model 512, 8 heads of 64, d_ff % 256 == 0.
  * The struct is HOST memory, read during the call only; every pointer in it is a device pointer.
  * forward : reads x and the parameters; writes y and `saved`; uses `scratch` (fwd_scratch_bytes).

@@ -1,6 +1,6 @@
 // One encoder layer per host call (bf16): cwlt_encoder_layer_fwd / _bwd enqueue the whole post-LN layer of
 // fast_transformers' TransformerEncoderLayer + AttentionLayer + CausalLinearAttention (built at
-// /root/reference/dqn_policy/model.py:128-137, called :232) on one stream -- 8 launches forward, 19-21 backward -- through
+// /root/reference/dqn_policy/model.py:128-137, called :232) on one stream -- 8 launches forward, 13-21 backward -- through
 // the same entry points the per-op path uses, so both produce the same kernels' results.
 //
 // Why: at the reference's own RL setting (30 windows x 50 tokens, IRL_dqn_train.py:267-345, ppo_train.py:365-417) an
