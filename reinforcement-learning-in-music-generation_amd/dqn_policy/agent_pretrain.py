@@ -9,13 +9,12 @@ import time
 
 import numpy as np
 import torch
-import torch.optim as optim
 
 _ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if _ROOT not in sys.path:
     sys.path.insert(0, _ROOT)
 import rlmg_amd  # noqa: E402,F401
-from rlmg_amd import data as cwdata, dist as rdist  # noqa: E402
+from rlmg_amd import data as cwdata, dist as rdist, ops  # noqa: E402
 
 try:
     from model import LinearTransformer, network_paras
@@ -59,7 +58,7 @@ def train(n_epoch=None, compute_dtype=torch.float32, log=print):
     if saver_agent:
         saver_agent.add_summary_msg(" > params amount: {:,d}".format(network_paras(net)))
     sync = rdist.GradSync(net.parameters())
-    optimizer = optim.Adam(net.parameters(), lr=init_lr)
+    optimizer = ops.graph_adam(net.parameters(), lr=init_lr)     # torch.optim.Adam, single-kernel form on the GPU
     train_x = np.concatenate((train_data["x"][:, :, :3], train_data["x"][:, :, 4:]), axis=2)
     train_y = np.concatenate((train_data["y"][:, :, :3], train_data["y"][:, :, 4:]), axis=2)
     train_mask = train_data["mask"]
